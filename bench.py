@@ -1,0 +1,323 @@
+#!/usr/bin/env python3
+"""
+bench.py -- latent-px/s of the tile-blend + tiled-VAE-decode hot path on an 8K image (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = the whole hot path for ONE 8192x8192 image (latent 1024x1024, SDXL config of BASELINE.json):
+    `--evals` (20) model evaluations of  [ tile gather (K2) -> overlap blend (K3-K7) ]   with 128x128 tiles, overlap 8,
+    then ONE tiled VAE decode of the latent (decoder tile 256 = upstream's default for > 30 GB, fast mode).
+The UNet itself is out of scope: the blend consumes pre-generated, HBM-resident tile outputs
+~N(0,1); the VAE is an SD/SDXL-shaped decoder (ch=128, ch_mult 1-2-4-4) with seeded random weights (no checkpoints
+offline).  Inputs are resident in HBM before the timed region; nothing is cached between steps.
+
+N > 1: strong scaling of the same image -- diffusion tiles in row bands per rank with a neighbour halo exchange of the
+overlap-row partial sums, VAE tiles dealt round-robin, outputs left sharded (mdtile/sharding.py).
+The JSON line carries `roofline` (dominant kernel: the fp32-MFMA 3x3 conv), `roofline_blend` (HBM-bound blend kernel) and
+`cpu_baseline` (the oracle = CPU port of the reference algorithm, timed on this box's host cores on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PLUGIN = os.path.join(ROOT, "multidiffusion-upscaler-for-automatic1111_amd")
+for _p in (ROOT, PLUGIN):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--latent", type=int, default=1024, help="latent side (1024 = 8192x8192 image)")
+    ap.add_argument("--tile", type=int, default=128)
+    ap.add_argument("--overlap", type=int, default=8)
+    ap.add_argument("--tile-bs", type=int, default=4)
+    ap.add_argument("--evals", type=int, default=20, help="model evaluations (sampler steps) per image")
+    ap.add_argument("--method", default="md", choices=["md", "mod"])
+    ap.add_argument("--vae-tile", type=int, default=256)
+    ap.add_argument("--slow-vae", action="store_true", help="slow-mode GroupNorm (pooled per norm) instead of fast mode")
+    ap.add_argument("--no-vae", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-vae-latent", type=int, default=96)
+    return ap.parse_args()
+
+
+class Profile:
+    """Per-launch HIP-event timing of the engine's kernels on torch's current stream (the stream they are launched on)."""
+
+    def __init__(self):
+        self.records = []   # (tag, work, start_event, end_event)
+
+    def wrap(self, tag, work, fn):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        out = fn()
+        e.record()
+        self.records.append((tag, work, s, e))
+        return out
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for tag, work, s, e in self.records:
+            a = agg.setdefault(tag, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += work
+            a[2] += s.elapsed_time(e) * 1e-3
+        return agg
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback path exists in the product)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    from oracle import stub_host as sh   # stub A1111 host (test infra) to drive the plugin without a webui
+    sh.install(dev)
+    sh.set_device(dev)
+    pl = sh.load_plugin()
+    E = pl.engine
+    from mdtile import sharding
+    from oracle import ldm_decoder as ld  # only for the random-weight SD-shaped decoder definition
+
+    L, N, C = args.latent, 2, 4
+    method = E.METHOD_MD if args.method == "md" else E.METHOD_MOD
+
+    # ------------------------------------------------------------------ blend state (init time, untimed)
+    plan = E.Plan(L, L, args.tile, args.tile, args.overlap, args.tile_bs)
+    weights = torch.zeros(1, 1, L, L, device=dev)
+    tile_w = E.gaussian_weights(plan.tile_w, plan.tile_h, dev) if args.method == "mod" else None
+    E.weight_map_add_grid(plan, tile_w, weights)
+    rescale = E.reciprocal(weights) if args.method == "mod" else None
+    ys = sorted(set(b[1] for b in plan.bboxes))
+    bands = sharding.band_partition(ys, plan.tile_h, plan.cols, L, world)
+    band = bands[rank]
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x_in = torch.randn(N, C, L, L, generator=g).to(dev)
+    # pre-generated model outputs for THIS rank's tiles (packed [T_local*N, C, th, tw]); seeded per tile so that any
+    # sharding sees the same data
+    g1 = torch.Generator(device="cpu").manual_seed(1)
+    all_tiles = None
+    n_local = band.tile_hi - band.tile_lo
+    if world == 1:
+        tile_out = torch.randn(plan.num_tiles * N, C, plan.tile_h, plan.tile_w, generator=g1).to(dev)
+    else:
+        full = torch.randn(plan.num_tiles * N, C, plan.tile_h, plan.tile_w, generator=g1)
+        tile_out = torch.zeros(plan.num_tiles * N, C, plan.tile_h, plan.tile_w, device=dev)
+        tile_out[band.tile_lo * N:band.tile_hi * N] = full[band.tile_lo * N:band.tile_hi * N].to(dev)
+        del full
+    x_tiles = torch.empty_like(tile_out)
+    blend_out = torch.empty(N, C, L, L, device=dev)
+    partial = torch.zeros(N, C, L, L, device=dev) if world > 1 else None
+    kw = dict(weights=weights) if args.method == "md" else dict(tile_w=tile_w, rescale=rescale)
+
+    def blend_eval():
+        E.gather_range(plan, x_in, x_tiles, band.tile_lo, band.tile_hi)      # K2 (this rank's tiles, packed, one launch)
+        if world == 1:
+            E.blend(plan, method, [tile_out], N, C, out=blend_out, packed=True, **kw)
+        elif not band.empty:
+            E.blend(plan, method, [tile_out], N, C, out=partial, packed=True, partial=True,
+                    tile_range=(band.tile_lo, band.tile_hi), row_range=(band.row_lo, band.row_hi), **kw)
+            sharding.exchange_and_sum(partial, bands, rank)
+            E.blend_finalize(plan, method, partial, weights=weights if args.method == "md" else None, out=blend_out,
+                             row_range=(band.row_lo, band.row_hi))
+
+    # ------------------------------------------------------------------ VAE state
+    hook = None
+    if not args.no_vae:
+        dec = ld.make_decoder(0).to(dev)
+        dec.original_forward = dec.forward
+        hook = pl.tilevae.VAEHook(dec, args.vae_tile, is_decoder=True, fast_decoder=not args.slow_vae, fast_encoder=False, color_fix=False)
+        hook.shard = (rank, world)
+        z = torch.randn(1, 4, L, L, generator=torch.Generator(device="cpu").manual_seed(2)).to(dev)
+
+    def step():
+        for _ in range(args.evals):
+            blend_eval()
+        if hook is not None:
+            return hook(z)
+
+    # ------------------------------------------------------------------ timed region
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    import builtins
+    _print = builtins.print
+    builtins.print = lambda *a, **k: None   # keep the plugin's progress chatter out of the JSON line
+    try:
+        for _ in range(args.warmup):
+            step()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        # per-stage split, untimed extras (same work, separate clocks)
+        sync_all()
+        tb = time.perf_counter()
+        for _ in range(args.evals):
+            blend_eval()
+        sync_all()
+        t_blend_eval = (time.perf_counter() - tb) / args.evals
+        t_vae = None
+        if hook is not None:
+            tv = time.perf_counter()
+            hook(z)
+            sync_all()
+            t_vae = time.perf_counter() - tv
+    finally:
+        builtins.print = _print
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    ms_per_step = elapsed / args.steps * 1e3
+    value = L * L / (elapsed / args.steps)
+
+    # ------------------------------------------------------------------ per-kernel roofline (instrumented extra pass)
+    roofline = roofline_blend = None
+    if rank == 0:
+        prof = Profile()
+        s_bytes = 4
+        T_local = plan.num_tiles if world == 1 else n_local
+        blend_bytes = s_bytes * (T_local * N * C * plan.tile_h * plan.tile_w + N * C * L * (L if world == 1 else band.row_hi - band.row_lo)) \
+            + 4 * L * (L if world == 1 else band.row_hi - band.row_lo) * (1 if args.method == "md" else 2)
+        for _ in range(20):
+            if world == 1:
+                prof.wrap("blend", blend_bytes, lambda: E.blend(plan, method, [tile_out], N, C, out=blend_out, packed=True, **kw))
+        if hook is not None:
+            orig_call = E.PackedConv.__call__
+
+            def timed_call(self, x, residual=None, upsample2x=False, token_major=False):
+                B, cin, H, W = x.shape
+                if upsample2x:
+                    H, W = 2 * H, 2 * W
+                flops = 2.0 * B * H * W * self.cout * cin * self.ksize * self.ksize
+                tag = f"conv{self.ksize}x{self.ksize}_{'wide' if ((self.cout + 31) // 32 * 32) > 64 else 'narrow'}"
+                return prof.wrap(tag, flops, lambda: orig_call(self, x, residual, upsample2x, token_major))
+
+            orig_attn = E.vae_attn
+
+            def timed_attn(q, k, v, scale):
+                B, Cc, T = q.shape
+                return prof.wrap("attn", 4.0 * B * T * T * Cc, lambda: orig_attn(q, k, v, scale))
+
+            E.PackedConv.__call__ = timed_call
+            E.vae_attn = timed_attn
+            builtins.print = lambda *a, **k: None
+            try:
+                hook(z)
+            finally:
+                builtins.print = _print
+                E.PackedConv.__call__ = orig_call
+                E.vae_attn = orig_attn
+        agg = prof.summary()
+        if "blend" in agg:
+            n, work, secs = agg["blend"]
+            ach = work / secs / 1e9
+            roofline_blend = {"kernel": "k_blend", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "launches": n,
+                              "avg_us": round(secs / n * 1e6, 2), "bytes_per_launch": int(work / n)}
+        conv_tags = {k: v for k, v in agg.items() if k.startswith("conv") or k == "attn"}
+        if conv_tags:
+            dom = max(conv_tags, key=lambda k_: conv_tags[k_][2])
+            n, work, secs = conv_tags[dom]
+            ach = work / secs / 1e12
+            roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None, "launches": n,
+                        "avg_us": round(secs / n * 1e6, 1), "flops_per_launch": work / n,
+                        "breakdown_s": {k: round(v[2], 4) for k, v in sorted(agg.items())},
+                        "breakdown_tflops": {k: round(v[1] / v[2] / 1e12, 2) for k, v in sorted(conv_tags.items())}}
+        elif roofline_blend is not None:
+            roofline = roofline_blend
+
+    # ------------------------------------------------------------------ CPU baseline (oracle = port of the reference), rank 0, N=1
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import blend_oracle as bo, vae_oracle as vo
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        o = bo.BlendOracle(args.method, L, L, args.tile, args.tile, args.overlap, args.tile_bs)
+        xc = x_in.cpu()
+        pre = [t.cpu() for t in torch.split(tile_out, [len(b) * N for b in plan.batches])]
+        it = iter(())
+
+        def replay(_x):
+            return next(it)
+
+        ts = []
+        for _ in range(4):
+            it = iter(pre)
+            t0 = time.perf_counter()
+            o.evaluate(xc, replay)
+            ts.append(time.perf_counter() - t0)
+        cpu_blend = sorted(ts)[len(ts) // 2]
+        sample = f"blend: median of 4 full {L}x{L} evaluations"
+        cpu_val = L * L / (args.evals * cpu_blend)
+        if hook is not None:
+            cl = args.cpu_vae_latent
+            dcpu = ld.make_decoder(0)
+            zc = torch.randn(1, 4, cl, cl, generator=torch.Generator().manual_seed(2))
+            t0 = time.perf_counter()
+            vo.tiled_forward(dcpu, zc, 64, fast=not args.slow_vae)
+            cpu_vae = time.perf_counter() - t0
+            per_px = args.evals * cpu_blend / (L * L) + cpu_vae / (cl * cl)
+            cpu_val = 1.0 / per_px
+            sample += f"; VAE: one tiled decode of a {cl}x{cl} latent at decoder tile 64 (the reference's CPU default), {cpu_vae:.1f} s; rates combined per latent px"
+        cpu_baseline = {"value": round(cpu_val, 1), "unit": "latent-px/s", "cores": cores, "kind": "port", "sample": sample,
+                        "blend_eval_ms": round(cpu_blend * 1e3, 2)}
+
+    if rank == 0:
+        out = {
+            "metric": "latent-px/sec tile-blend+VAE-decode, 8K image", "value": round(value, 1), "unit": "latent-px/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"SDXL 8192x8192 (latent {L}x{L}): {args.evals} x [tile gather + {'MultiDiffusion' if args.method == 'md' else 'Mixture-of-Diffusers'} "
+                                   f"blend, {plan.num_tiles} tiles {plan.tile_w}x{plan.tile_h} overlap {plan.overlap}, N=2,C=4] + "
+                                   + ("no VAE" if hook is None else f"tiled VAE decode (tile {args.vae_tile}, {'slow' if args.slow_vae else 'fast'} mode, SD decoder ch=128, random weights)"),
+                       "latent": [L, L], "tile": [plan.tile_w, plan.tile_h], "overlap": plan.overlap, "evals": args.evals,
+                       "vae_tile": None if hook is None else args.vae_tile, "sharding": "none" if world == 1 else f"tile-row bands x{world} + halo exchange; VAE tiles round-robin"},
+            "stage_ms": {"blend_eval": round(t_blend_eval * 1e3, 4), "vae_decode": None if t_vae is None else round(t_vae * 1e3, 2)},
+            "stage_px_per_s": {"blend_eval": round(L * L / t_blend_eval, 1), "vae_decode": None if t_vae is None else round(L * L / t_vae, 1)},
+            "roofline": roofline, "roofline_blend": roofline_blend, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,221 @@
+/*
+ * mdtile.h -- C ABI of the MI355X-native tiled-diffusion / tiled-VAE engine (libmdtile.so).
+ *
+ * This is the drop-in boundary below the A1111 plugin surface (SURVEY.md section 8b "inner boundary").
+ * The upstream extension is pure Python and has no FFI of its own; each entry point below replaces the torch
+ * op sequence at the cited upstream call site (paths relative to the upstream repo root).  The Python host
+ * (multidiffusion-upscaler-for-automatic1111_amd/mdtile/) binds these with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - plain C types only; every device buffer is owned by the caller (PyTorch), the library allocates nothing on
+ *     the device except the small index tables inside an opaque plan
+ *   - every launch is asynchronous on the hipStream_t passed as `stream` (void* here; NULL = default stream)
+ *   - return value: 0 = ok, negative = error (see MDTILE_E_*); mdtile_last_error() gives text; nothing throws/aborts
+ *   - tensors are dense NCHW; "f32"/"f16"/"bf16" I/O selected by MDTILE_DT_*; all accumulation is fp32
+ *   - not re-entrant on one plan; one plan per host thread
+ */
+#ifndef MDTILE_H
+#define MDTILE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDTILE_VERSION 100
+
+#define MDTILE_OK 0
+#define MDTILE_E_ARG (-1)      /* bad argument / unsupported shape */
+#define MDTILE_E_HIP (-2)      /* HIP runtime error               */
+#define MDTILE_E_LIMIT (-3)    /* compile-time capacity exceeded  */
+
+#define MDTILE_DT_F32 0
+#define MDTILE_DT_F16 1
+#define MDTILE_DT_BF16 2
+
+#define MDTILE_METHOD_MD 0     /* MultiDiffusion            (tile_methods/multidiffusion.py)      */
+#define MDTILE_METHOD_MOD 1    /* Mixture of Diffusers      (tile_methods/mixtureofdiffusers.py)  */
+
+#define MDTILE_REGION_BG 0     /* BlendMode.BACKGROUND (tile_utils/utils.py:36-39) */
+#define MDTILE_REGION_FG 1     /* BlendMode.FOREGROUND */
+
+#define MDTILE_MAX_BATCHES 320 /* tile-batch pointers carried in kernel arguments */
+#define MDTILE_MAX_REGIONS 16  /* = upstream md_max_regions cap (scripts/tilediffusion.py:81) */
+
+typedef void* mdtile_stream_t; /* hipStream_t */
+typedef struct mdtile_plan mdtile_plan;
+
+int mdtile_version(void);
+const char* mdtile_last_error(void);
+
+/* ----------------------------------------------------------------------------------------------------------
+ * Grid planning (host integers only).
+ * Replaces split_bboxes (tile_utils/utils.py:160-177) + init_grid_bbox (tile_methods/abstractdiffusion.py:173-186):
+ *   tile := min(tile, canvas); overlap := max(0, min(overlap, min(tile_w_req, tile_h_req) - 4));
+ *   cols = ceil((w-ov)/(tw-ov)); dx = (w-tw)/(cols-1) (double); x_c = min(int(c*dx), w-tw); rows likewise;
+ *   num_batches = ceil(T/tile_bs); tile_bs := ceil(T/num_batches).
+ * w,h,tile_*,overlap are in latent pixels.  The plan owns small device tables (origins, per-column / per-row
+ * covering ranges) used by the gather-formulated kernels below.
+ * -------------------------------------------------------------------------------------------------------- */
+mdtile_plan* mdtile_plan_create(int w, int h, int tile_w, int tile_h, int overlap, int tile_bs, int clamp);
+/* clamp = 1: init_grid_bbox semantics (tile and overlap clamped as above); clamp = 0: raw split_bboxes(w,h,tw,th,overlap) */
+void mdtile_plan_destroy(mdtile_plan* plan);
+/* info[8] = { cols, rows, num_tiles, num_batches, tile_bs, tile_w, tile_h, overlap_effective } */
+int mdtile_plan_info(const mdtile_plan* plan, int* info8);
+/* xywh[4*num_tiles], row-major tile order (y outer) == upstream bbox list order */
+int mdtile_plan_bboxes(const mdtile_plan* plan, int* xywh);
+
+/* ----------------------------------------------------------------------------------------------------------
+ * Weight maps (init time, device).
+ * -------------------------------------------------------------------------------------------------------- */
+/* gaussian_weights (tile_utils/utils.py:180-194): d_out[tile_h*tile_w] fp32; profile evaluated in fp64, var=0.01,
+ * both axes normalised by tile_w^2, x midpoint (tile_w-1)/2, y midpoint tile_h/2. */
+int mdtile_gaussian_weights(int tile_w, int tile_h, float* d_out, mdtile_stream_t stream);
+/* feather_mask (tile_utils/utils.py:196-214): d_out[h*w] fp32. */
+int mdtile_feather_mask(int w, int h, double ratio, float* d_out, mdtile_stream_t stream);
+/* Grid weight map: the `weight[bbox.slicer] += init_weight` loop of split_bboxes (utils.py:164-175) followed by
+ * `self.weights += weights` (abstractdiffusion.py:181-182).  d_tile_w == NULL -> uniform 1.0 (MultiDiffusion),
+ * else the [tile_h, tile_w] Gaussian (Mixture of Diffusers).  d_weights[h*w] is updated in place. */
+int mdtile_weight_map_add_grid(const mdtile_plan* plan, const float* d_tile_w, float* d_weights, mdtile_stream_t stream);
+/* Region contribution: `self.weights[bbox.slicer] += 1.0` (multidiffusion.py:44-46, d_rect_w == NULL, scalar used) or
+ * `+= gaussian_weights(bbox.w, bbox.h)` (mixtureofdiffusers.py:50-53).  Canvas is [H, W]. */
+int mdtile_weight_map_add_rect(float* d_weights, int W, int H, int x, int y, int w, int h, const float* d_rect_w,
+                               float scalar, mdtile_stream_t stream);
+/* rescale_factor = 1 / weights (mixtureofdiffusers.py:32); inf where weights == 0, as upstream. */
+int mdtile_reciprocal(const float* d_in, float* d_out, size_t n, mdtile_stream_t stream);
+/* custom_weights[i] *= rescale_factor[bbox.slicer] (mixtureofdiffusers.py:34-36); d_rect_w[h*w] in place. */
+int mdtile_rect_mul_canvas(float* d_rect_w, const float* d_canvas, int W, int H, int x, int y, int w, int h,
+                           mdtile_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------------------------
+ * Tile gather (K2): x_tile[i*N + n, c, :, :] = x_in[n, c, y_i:y_i+th, x_i:x_i+tw]  (tile-major batch layout)
+ * Replaces `torch.cat([x_in[bbox.slicer] for bbox in bboxes], dim=0)` (multidiffusion.py:155,
+ * mixtureofdiffusers.py:88,104).  mdtile_gather_all fills every batch in ONE launch (batch_ptrs[num_batches]).
+ * -------------------------------------------------------------------------------------------------------- */
+int mdtile_gather(const mdtile_plan* plan, int dtype, int N, int C, const void* d_x_in, int batch_id, void* d_x_tile,
+                  mdtile_stream_t stream);
+int mdtile_gather_all(const mdtile_plan* plan, int dtype, int N, int C, const void* d_x_in, void* const* batch_ptrs,
+                      int num_batches, mdtile_stream_t stream);
+/* Tiles [tile_lo, tile_hi) only, into ONE packed buffer laid out as [T*N, C, th, tw] (tile t at row t*N): the multi-GPU
+ * path gathers just the rank's band of tile rows. */
+int mdtile_gather_range(const mdtile_plan* plan, int dtype, int N, int C, const void* d_x_in, void* d_packed, int tile_lo,
+                        int tile_hi, mdtile_stream_t stream);
+/* Arbitrary-rect gather for custom regions: `x_in[bbox.slicer]` (multidiffusion.py:184, mixtureofdiffusers.py:140). */
+int mdtile_gather_rect(int dtype, int N, int C, int W, int H, const void* d_x_in, int x, int y, int w, int h,
+                       void* d_out, mdtile_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------------------------
+ * Overlap blend (K3..K7), gather-formulated: one thread owns output pixels, sums the covering tile values in
+ * upstream's tile order (so fp32 results are bit-identical to the sequential `+=` loop), then applies the
+ * method's epilogue.  ONE launch per model evaluation.
+ *
+ *   MD  (multidiffusion.py:147-216):  buf = sum_tiles out_t (+ sum_bg out_r);  x = weights > 1 ? buf / weights : buf
+ *   MoD (mixtureofdiffusers.py:74-175): buf = sum_tiles out_t * (tile_w * rescale[slicer]) (+ sum_bg out_r * cw_r)
+ *   both: foreground regions: fbuf += out_r, fmask += feather_r, fcnt += 1; averaged where fcnt > 1;
+ *         x = fcnt > 0 ? x * (1 - fmask) + fbuf * fmask : x
+ *
+ * batch_out[b] : device pointer to the model output of tile batch b, [nb_b*N, C, tile_h, tile_w] (tile-major)
+ *                num_batches == 0  <=>  draw_background == False (abstractdiffusion.py:199-201)
+ * regions      : in upstream list order
+ * flags        : MDTILE_BLEND_PARTIAL = write raw partial sums (buf only, no epilogue) -- the multi-GPU path sums
+ *                partials across ranks and then calls mdtile_blend_finalize.
+ * -------------------------------------------------------------------------------------------------------- */
+typedef struct mdtile_region {
+    int x, y, w, h;
+    int mode;            /* MDTILE_REGION_BG | MDTILE_REGION_FG */
+    int _pad;
+    const void* out;     /* model output for the region, [N, C, h, w], dtype as the call */
+    const float* weight; /* BG+MoD: pre-multiplied custom weight [h,w]; FG: feather mask [h,w]; BG+MD: NULL */
+} mdtile_region;
+
+#define MDTILE_BLEND_PARTIAL 1
+#define MDTILE_BLEND_TILE_RANGE 2 /* only tiles with tile_lo <= index < tile_hi contribute (row-band sharding) */
+#define MDTILE_BLEND_PACKED 4     /* batch_out[0] is ONE packed buffer [T*N, C, th, tw] holding every tile (any T) */
+
+typedef struct mdtile_blend_args {
+    int method;                  /* MDTILE_METHOD_* */
+    int dtype;                   /* MDTILE_DT_* of batch_out / region out / x_out */
+    int N, C;
+    int flags;
+    int tile_lo, tile_hi;        /* with MDTILE_BLEND_TILE_RANGE */
+    int row_lo, row_hi;          /* canvas rows to produce [row_lo,row_hi); 0,0 = all */
+    const float* d_weights;      /* MD : [H,W] weight-sum map                                        */
+    const float* d_tile_w;       /* MoD: [tile_h, tile_w] Gaussian                                    */
+    const float* d_rescale;      /* MoD: [H,W] 1/weights                                              */
+    void* d_x_out;               /* [N,C,H,W]; with PARTIAL: fp32 [N,C,H,W] raw sums                  */
+} mdtile_blend_args;
+
+int mdtile_blend(const mdtile_plan* plan, const mdtile_blend_args* args, const void* const* batch_out, int num_batches,
+                 const mdtile_region* regions, int num_regions, mdtile_stream_t stream);
+/* Epilogue on summed partials (multi-GPU): MD divide + FG composite, identical math to mdtile_blend's tail.
+ * d_partial fp32 [N,C,H,W]; FG regions are re-read from `regions`. */
+int mdtile_blend_finalize(const mdtile_plan* plan, const mdtile_blend_args* args, const float* d_partial,
+                          const mdtile_region* regions, int num_regions, mdtile_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------------------------
+ * Tiled VAE (scripts/tilevae.py).  All tensors fp32 NCHW.
+ * -------------------------------------------------------------------------------------------------------- */
+/* split_tiles + get_best_tile_size (tilevae.py:390-462).  in_bboxes/out_bboxes: [4*n] as [x1,x2,y1,y2].
+ * Returns the tile count (>=1) or a negative error; pass cap = capacity in tiles (call with cap=0 to query). */
+int mdtile_vae_split_tiles(int h, int w, int tile_size, int is_decoder, int* in_bboxes, int* out_bboxes, int cap);
+
+/* get_var_mean (tilevae.py:207-215): biased var & mean per (sample, group); x [B,C,HW]; out [B*groups] each.
+ * Deterministic two-stage reduction (fp64 accumulators, no atomics); d_ws: mdtile_gn_stats_ws_size(B, groups) bytes. */
+size_t mdtile_gn_stats_ws_size(int B, int groups);
+int mdtile_gn_stats(const float* d_x, int B, int C, int HW, int groups, float* d_mean, float* d_var, void* d_ws,
+                    mdtile_stream_t stream);
+/* GroupNormParam.summary (tilevae.py:320-335): pixel-weighted pooling of T per-tile stat rows.
+ * d_means/d_vars [T, BG]; d_frac[T] = the normalised pixel fractions p_i (tilevae.py:328-331, T host-side floats
+ * computed by the caller and copied to the device); out [BG]:  var = sum_i p_i var_i, mean = sum_i p_i mean_i. */
+int mdtile_gn_pool(const float* d_means, const float* d_vars, const float* d_frac, int T, int BG, float* d_mean,
+                   float* d_var, mdtile_stream_t stream);
+/* custom_group_norm (tilevae.py:218-245) fused with the following in-place SiLU (tilevae.py:102-104):
+ * y = ((x - mean_g) / sqrt(var_g + eps)) * gamma_c + beta_c ; if silu: y = y * sigmoid(y).  gamma/beta may be NULL.
+ * In place (d_y == d_x) allowed. */
+int mdtile_gn_apply(const float* d_x, float* d_y, int B, int C, int HW, int groups, const float* d_mean,
+                    const float* d_var, const float* d_gamma, const float* d_beta, float eps, int silu,
+                    mdtile_stream_t stream);
+/* standalone SiLU / residual add (queue tasks 'silu', 'add_res', tilevae.py:102-104, 614-616) */
+int mdtile_silu(const float* d_x, float* d_y, size_t n, mdtile_stream_t stream);
+int mdtile_add(const float* d_a, const float* d_b, float* d_y, size_t n, mdtile_stream_t stream);
+
+/* Conv tiles (queue tasks conv_in/conv1/conv2/nin_shortcut/upsample/conv_out/q/k/v/proj_out, tilevae.py:115-195).
+ * stride 1, 'same' zero padding, ksize 1 or 3.  Weights are pre-packed once by mdtile_conv_pack (OIHW -> [tap][cin][cout]).
+ *   MDTILE_CONV_UPSAMPLE2X : input is read through a nearest 2x upsample (ldm Upsample: interpolate then conv)
+ *   d_residual != NULL     : y = conv(x) + bias + residual   ('add_res' fused)
+ *   out_layout             : 0 = [B,Cout,H,W];  1 = token-major [B,H*W,Cout] (V operand of mdtile_vae_attn)
+ * H, W are the OUTPUT spatial size. */
+#define MDTILE_CONV_UPSAMPLE2X 1
+size_t mdtile_conv_packed_size(int cout, int cin, int ksize); /* floats */
+int mdtile_conv_pack(const float* d_w_oihw, float* d_w_packed, int cout, int cin, int ksize, mdtile_stream_t stream);
+int mdtile_conv2d(const float* d_x, const float* d_w_packed, const float* d_bias, const float* d_residual, float* d_y,
+                  int B, int cin, int cout, int H, int W, int ksize, int flags, int out_layout, mdtile_stream_t stream);
+
+/* attn_forward body between the 1x1 convs (tile_utils/attn.py:55-70): single head,
+ * out[b,c,i] = sum_j v[b,c,j] * softmax_j(scale * sum_c' q[b,c',i] k[b,c',j]).
+ * q,k: [B,C,T] channel-major;  v: [B,T,C] token-major (conv out_layout 1);  out: [B,C,T].  C multiple of 64.
+ * d_ws: workspace of mdtile_vae_attn_ws_size(B,C,T) bytes. */
+size_t mdtile_vae_attn_ws_size(int B, int C, int T);
+int mdtile_vae_attn(const float* d_q, const float* d_k, const float* d_v, float* d_out, int B, int C, int T, float scale,
+                    void* d_ws, mdtile_stream_t stream);
+
+/* crop_valid_region + result[...] = tile (tilevae.py:248-259, 630-632): copies the valid window of one finished tile
+ * [N,C,th,tw] into result [N,C,RH,RW].  in_bbox/out_bbox as returned by mdtile_vae_split_tiles. */
+int mdtile_crop_store(const float* d_tile, int N, int C, int th, int tw, const int* in_bbox4, const int* out_bbox4,
+                      int is_decoder, float* d_result, int RH, int RW, mdtile_stream_t stream);
+/* tile extraction z[:, :, y1:y2, x1:x2] (tilevae.py:532-535) == mdtile_gather_rect with dtype f32 */
+
+/* fast-mode estimator input (tilevae.py:545-559): scale_factor = tile_size / max(H, W); nearest-exact resample of
+ * z [N,C,H,W] to [N,C,oh,ow] (sizes from mdtile_vae_fast_size), per-channel re-standardisation (unbiased std over
+ * N,H,W of both), clamp to [min z, max z].  d_ws: mdtile_vae_fast_ws_size(C) bytes. */
+int mdtile_vae_fast_size(int H, int W, int tile_size, int* oh, int* ow);
+size_t mdtile_vae_fast_ws_size(int C);
+int mdtile_vae_fast_input(const float* d_z, int N, int C, int H, int W, int tile_size, float* d_out, void* d_ws,
+                          mdtile_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDTILE_H */

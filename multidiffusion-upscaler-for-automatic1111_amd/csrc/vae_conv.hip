@@ -1,0 +1,247 @@
+// Conv tiles of the Tiled-VAE task queue (K15, K16): implicit-GEMM 3x3 / 1x1 convolution on the fp32 matrix cores.
+// Upstream runs these as nn.Conv2d modules held by the queue (scripts/tilevae.py:115-195: conv_in, conv1, conv2,
+// nin_shortcut, upsample.conv, conv_out, and q/k/v/proj_out of tile_utils/attn.py:50-70), plus a separate in-place
+// residual add (tilevae.py:614-616) and F.interpolate(nearest, 2x) before the upsample conv.
+//
+// Design (gfx950):
+//   * exact fp32: v_mfma_f32_32x32x2_f32 (bit-identical to an fmaf chain; 157 TFLOP/s peak, no TF32 on CDNA4)
+//   * NCHW in, NCHW (or token-major) out.  GEMM view:  D[cout][px] = sum_{tap,cin} Wp[tap][cin][cout] * X[cin][px+tap]
+//     M = 32 output channels per MFMA, N = 32 consecutive pixels of one image row, K = 2 input channels of one tap.
+//     Both operands are K-major in LDS, so every ds_read_b32 is a conflict-free 32-lane run.
+//   * block = 4 waves, output tile 8 rows x 32 px x BN channels; the (8+2)x(32+2) input halo of a KC-channel slab is
+//     staged once in LDS and re-read by all 9 taps (9x on-chip reuse) - global traffic is 1 read of X per BN-block.
+//   * register-prefetch double buffering: the next slab's global loads are issued before the current slab's MFMAs and
+//     written to the other LDS buffer after them: one barrier per slab.
+//   * nearest-2x upsample and the residual add are fused (source index >> 1 while staging; epilogue add).
+//   * XCD-aware block order: the BN-blocks of one pixel tile sit on the same XCD (same L2) back to back.
+#include "common.h"
+
+using namespace mdt;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+struct ConvParams {
+    const float* x;         // [B, Cin, Hin, Win]
+    const float* w;         // packed [KS*KS][Cin][CoutP]
+    const float* bias;      // [Cout] or null
+    const float* res;       // residual, same layout as y, or null
+    float* y;
+    int B, Cin, Cout, CoutP, H, W;  // H, W: OUTPUT spatial size
+    int Hin, Win, up;               // input spatial size; up = 1 for fused nearest-2x
+    int ptiles, PX, NCB;
+};
+
+template <int KS, int KC, int WP, int WC, int RP, int RC, bool TOKMAJ>
+__global__ __launch_bounds__(256) void k_conv(const ConvParams P) {
+    static_assert(WP * WC == 4 && WP * RP == 8, "4 waves cover 8 rows");
+    constexpr int PAD = KS / 2, ROWS = 8 + KS - 1, TWP = 32 + KS - 1, TAPS = KS * KS, BN = WC * RC * 32;
+    constexpr int E_IN = KC * ROWS * TWP, E_IN_P = (E_IN + 3) & ~3, E_WT = TAPS * KC * BN;
+    constexpr int NI = (E_IN + 255) / 256, NW = (E_WT / 4 + 255) / 256, BUF = E_IN_P + E_WT;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
+
+    // ---- block -> (pixel tile, channel block): XCD = id % 8 keeps all NCB channel blocks of a pixel tile on one L2
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int ptile = (slot / P.NCB) * 8 + xcd, cb = slot % P.NCB;
+    if (ptile >= P.ptiles) return;
+    const int b = blockIdx.y;
+    const int py = ptile / P.PX, px = ptile - py * P.PX;
+    const int y0 = py * 8, x0 = px * 32, n0 = cb * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    const int wp = wave / WC, wc = wave % WC;
+    const size_t HWin = (size_t)P.Hin * P.Win;
+    const float* xb = P.x + (size_t)b * P.Cin * HWin;
+
+    // ---- stage-independent staging maps
+    int goff[NI];  // (kc << 24) | offset inside a channel plane, or -1 (zero padding / outside)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int idx = tid + 256 * i;
+        goff[i] = -1;
+        if (idx < E_IN) {
+            const int kc = idx / (ROWS * TWP), rem = idx - kc * (ROWS * TWP);
+            const int r = rem / TWP, c = rem - r * TWP;
+            const int gy = y0 + r - PAD, gx = x0 + c - PAD;
+            if (gy >= 0 && gy < P.H && gx >= 0 && gx < P.W) {
+                const int sy = P.up ? gy >> 1 : gy, sx = P.up ? gx >> 1 : gx;
+                goff[i] = (kc << 24) | (sy * P.Win + sx);
+            }
+        }
+    }
+    float rin[NI];
+    float4 rwt[NW];
+
+    auto load_stage = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int g = goff[i];
+            const int kc = g >> 24;
+            rin[i] = (g >= 0 && c0 + kc < P.Cin) ? xb[(size_t)(c0 + kc) * HWin + (g & 0xffffff)] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int q = tid + 256 * i;  // float4 index in [tap][kc][BN/4]
+            const int n4 = q % (BN / 4), kc = (q / (BN / 4)) % KC, tap = q / (BN / 4) / KC;
+            const int cin = c0 + kc, n = n0 + 4 * n4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < E_WT / 4 && cin < P.Cin && n < P.CoutP)
+                v = *reinterpret_cast<const float4*>(P.w + ((size_t)tap * P.Cin + cin) * P.CoutP + n);
+            rwt[i] = v;
+        }
+    };
+    auto store_stage = [&](int buf) {
+        float* in_l = smem + buf * BUF;
+        float* wt_l = in_l + E_IN_P;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < E_IN) in_l[idx] = rin[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int q = tid + 256 * i;
+            if (q < E_WT / 4) reinterpret_cast<float4*>(wt_l)[q] = rwt[i];
+        }
+    };
+
+    f32x16 acc[RP][RC];
+#pragma unroll
+    for (int r = 0; r < RP; ++r)
+#pragma unroll
+        for (int j = 0; j < RC; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[r][j][q] = 0.0f;
+
+    const int nst = (P.Cin + KC - 1) / KC;
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    for (int st = 0; st < nst; ++st) {
+        if (st + 1 < nst) load_stage((st + 1) * KC);
+        const float* in_l = smem + (st & 1) * BUF;
+        const float* wt_l = in_l + E_IN_P;
+        // lane view: hi selects the k of the pair, l31 the pixel / the output channel
+        const float* inb = in_l + hi * (ROWS * TWP) + (wp * RP) * TWP + l31;
+        const float* wtb = wt_l + hi * BN + wc * (RC * 32) + l31;
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int dy = tap / KS, dx = tap % KS;
+#pragma unroll
+            for (int s = 0; s < KC / 2; ++s) {
+                float wv[RC], xv[RP];
+#pragma unroll
+                for (int j = 0; j < RC; ++j) wv[j] = wtb[(tap * KC + 2 * s) * BN + j * 32];
+#pragma unroll
+                for (int r = 0; r < RP; ++r) xv[r] = inb[(2 * s * ROWS + r + dy) * TWP + dx];
+#pragma unroll
+                for (int r = 0; r < RP; ++r)
+#pragma unroll
+                    for (int j = 0; j < RC; ++j) {
+                        if (TOKMAJ) acc[r][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[r], wv[j], acc[r][j], 0, 0, 0);
+                        else        acc[r][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j], xv[r], acc[r][j], 0, 0, 0);
+                    }
+            }
+        }
+        if (st + 1 < nst) store_stage((st + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: + bias (+ residual), store.  C/D layout of 32x32 MFMA: col = lane & 31, row = (q&3) + 8*(q>>2) + 4*hi
+    const size_t HW = (size_t)P.H * P.W;
+#pragma unroll
+    for (int r = 0; r < RP; ++r) {
+        const int y = y0 + wp * RP + r;
+        if (y >= P.H) continue;
+#pragma unroll
+        for (int j = 0; j < RC; ++j) {
+            const int cbase = n0 + (wc * RC + j) * 32;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = (q & 3) + 8 * (q >> 2) + 4 * hi;
+                if (!TOKMAJ) {  // rows = output channel, cols = pixel  ->  128-B runs along x
+                    const int co = cbase + row, x = x0 + l31;
+                    if (co < P.Cout && x < P.W) {
+                        const size_t o = ((size_t)b * P.Cout + co) * HW + (size_t)y * P.W + x;
+                        float v = acc[r][j][q] + (P.bias ? P.bias[co] : 0.0f);
+                        if (P.res) v += P.res[o];
+                        P.y[o] = v;
+                    }
+                } else {        // rows = pixel, cols = output channel  ->  128-B runs along c of [B, HW, Cout]
+                    const int co = cbase + l31, x = x0 + row;
+                    if (co < P.Cout && x < P.W) {
+                        const size_t o = ((size_t)b * HW + (size_t)y * P.W + x) * P.Cout + co;
+                        float v = acc[r][j][q] + (P.bias ? P.bias[co] : 0.0f);
+                        if (P.res) v += P.res[o];
+                        P.y[o] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+__global__ void k_conv_pack(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int KS, int CoutP) {
+    const size_t n = (size_t)KS * KS * Cin * CoutP;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int co = (int)(i % CoutP);
+    const int ci = (int)((i / CoutP) % Cin);
+    const int tap = (int)(i / ((size_t)CoutP * Cin));
+    wp[i] = co < Cout ? w[((size_t)co * Cin + ci) * KS * KS + tap] : 0.0f;  // OIHW, tap = ky*KS + kx
+}
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+template <int KS, int KC, int WP, int WC, int RP, int RC>
+int launch_conv(ConvParams& P, int out_layout, hipStream_t s) {
+    constexpr int BN = WC * RC * 32;
+    P.PX = (P.W + 31) / 32;
+    P.ptiles = P.PX * ((P.H + 7) / 8);
+    P.NCB = (P.CoutP + BN - 1) / BN;
+    dim3 grid(((P.ptiles + 7) / 8) * 8 * P.NCB, P.B), block(256);
+    if (out_layout == 1) hipLaunchKernelGGL((k_conv<KS, KC, WP, WC, RP, RC, true>), grid, block, 0, s, P);
+    else hipLaunchKernelGGL((k_conv<KS, KC, WP, WC, RP, RC, false>), grid, block, 0, s, P);
+    MDT_LAUNCH_CHECK();
+    return MDTILE_OK;
+}
+
+}  // namespace
+
+extern "C" size_t mdtile_conv_packed_size(int cout, int cin, int ksize) {
+    if (cout <= 0 || cin <= 0 || (ksize != 1 && ksize != 3)) return 0;
+    return (size_t)ksize * ksize * cin * round_up(cout, 32);
+}
+
+extern "C" int mdtile_conv_pack(const float* d_w_oihw, float* d_w_packed, int cout, int cin, int ksize, mdtile_stream_t stream) {
+    MDT_CHECK_ARG(d_w_oihw && d_w_packed && cout > 0 && cin > 0 && (ksize == 1 || ksize == 3), "mdtile_conv_pack: bad arguments");
+    const int CoutP = round_up(cout, 32);
+    const size_t n = (size_t)ksize * ksize * cin * CoutP;
+    hipLaunchKernelGGL(k_conv_pack, dim3(cdiv((long long)n, 256)), dim3(256), 0, as_stream(stream), d_w_oihw, d_w_packed, cout, cin, ksize, CoutP);
+    MDT_LAUNCH_CHECK();
+    return MDTILE_OK;
+}
+
+extern "C" int mdtile_conv2d(const float* d_x, const float* d_w_packed, const float* d_bias, const float* d_residual, float* d_y,
+                             int B, int cin, int cout, int H, int W, int ksize, int flags, int out_layout, mdtile_stream_t stream) {
+    MDT_CHECK_ARG(d_x && d_w_packed && d_y, "mdtile_conv2d: null argument");
+    MDT_CHECK_ARG(B > 0 && B <= 65535 && cin > 0 && cout > 0 && H > 0 && W > 0, "mdtile_conv2d: bad shape B=%d cin=%d cout=%d H=%d W=%d", B, cin, cout, H, W);
+    MDT_CHECK_ARG(ksize == 1 || ksize == 3, "mdtile_conv2d: ksize %d unsupported (1 or 3)", ksize);
+    MDT_CHECK_ARG(out_layout == 0 || out_layout == 1, "mdtile_conv2d: bad out_layout %d", out_layout);
+    const int up = (flags & MDTILE_CONV_UPSAMPLE2X) ? 1 : 0;
+    MDT_CHECK_ARG(!up || (H % 2 == 0 && W % 2 == 0), "mdtile_conv2d: upsample2x needs even output size, got %dx%d", H, W);
+    MDT_CHECK_ARG((size_t)(up ? H / 2 : H) * (up ? W / 2 : W) < (1u << 24), "mdtile_conv2d: input plane too large for the staging map");
+    ConvParams P;
+    P.x = d_x; P.w = d_w_packed; P.bias = d_bias; P.res = d_residual; P.y = d_y;
+    P.B = B; P.Cin = cin; P.Cout = cout; P.CoutP = round_up(cout, 32); P.H = H; P.W = W;
+    P.Hin = up ? H / 2 : H; P.Win = up ? W / 2 : W; P.up = up;
+    hipStream_t s = as_stream(stream);
+    const bool wide = P.CoutP > 64;
+    if (ksize == 3) {
+        if (wide) return launch_conv<3, 8, 2, 2, 4, 2>(P, out_layout, s);
+        return launch_conv<3, 8, 4, 1, 2, 1>(P, out_layout, s);
+    }
+    if (wide) return launch_conv<1, 16, 2, 2, 4, 2>(P, out_layout, s);
+    return launch_conv<1, 16, 4, 1, 2, 1>(P, out_layout, s);
+}

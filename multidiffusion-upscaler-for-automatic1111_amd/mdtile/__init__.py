@@ -1,0 +1,488 @@
+"""
+mdtile -- ctypes binding of libmdtile.so (include/mdtile.h) for the PyTorch-ROCm host.
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every hot-path computation happens in the
+hand-written gfx950 kernels behind the C ABI.  There is NO CPU / eager-torch fallback: if the shared library is
+missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_size_t, c_void_p
+from typing import List, Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmdtile.so")
+
+OK, E_ARG, E_HIP, E_LIMIT = 0, -1, -2, -3
+DT_F32, DT_F16, DT_BF16 = 0, 1, 2
+METHOD_MD, METHOD_MOD = 0, 1
+REGION_BG, REGION_FG = 0, 1
+BLEND_PARTIAL, BLEND_TILE_RANGE, BLEND_PACKED = 1, 2, 4
+CONV_UPSAMPLE2X = 1
+MAX_BATCHES, MAX_REGIONS = 320, 16
+
+_DTYPES = {torch.float32: DT_F32, torch.float16: DT_F16, torch.bfloat16: DT_BF16}
+
+
+class MdtileError(RuntimeError):
+    pass
+
+
+class _Region(ctypes.Structure):
+    _fields_ = [("x", c_int), ("y", c_int), ("w", c_int), ("h", c_int), ("mode", c_int), ("_pad", c_int),
+                ("out", c_void_p), ("weight", c_void_p)]
+
+
+class _BlendArgs(ctypes.Structure):
+    _fields_ = [("method", c_int), ("dtype", c_int), ("N", c_int), ("C", c_int), ("flags", c_int),
+                ("tile_lo", c_int), ("tile_hi", c_int), ("row_lo", c_int), ("row_hi", c_int),
+                ("d_weights", c_void_p), ("d_tile_w", c_void_p), ("d_rescale", c_void_p), ("d_x_out", c_void_p)]
+
+
+# every symbol include/mdtile.h declares: name -> (restype, argtypes)
+_IP = POINTER(c_int)
+_SIGNATURES = {
+    "mdtile_version": (c_int, []),
+    "mdtile_last_error": (c_char_p, []),
+    "mdtile_plan_create": (c_void_p, [c_int] * 7),
+    "mdtile_plan_destroy": (None, [c_void_p]),
+    "mdtile_plan_info": (c_int, [c_void_p, _IP]),
+    "mdtile_plan_bboxes": (c_int, [c_void_p, _IP]),
+    "mdtile_gaussian_weights": (c_int, [c_int, c_int, c_void_p, c_void_p]),
+    "mdtile_feather_mask": (c_int, [c_int, c_int, c_double, c_void_p, c_void_p]),
+    "mdtile_weight_map_add_grid": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mdtile_weight_map_add_rect": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_float, c_void_p]),
+    "mdtile_reciprocal": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mdtile_rect_mul_canvas": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mdtile_gather": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "mdtile_gather_all": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, POINTER(c_void_p), c_int, c_void_p]),
+    "mdtile_gather_range": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "mdtile_gather_rect": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "mdtile_blend": (c_int, [c_void_p, POINTER(_BlendArgs), POINTER(c_void_p), c_int, POINTER(_Region), c_int, c_void_p]),
+    "mdtile_blend_finalize": (c_int, [c_void_p, POINTER(_BlendArgs), c_void_p, POINTER(_Region), c_int, c_void_p]),
+    "mdtile_vae_split_tiles": (c_int, [c_int, c_int, c_int, c_int, _IP, _IP, c_int]),
+    "mdtile_gn_stats_ws_size": (c_size_t, [c_int, c_int]),
+    "mdtile_gn_stats": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mdtile_gn_pool": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "mdtile_gn_apply": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_float, c_int, c_void_p]),
+    "mdtile_silu": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mdtile_add": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mdtile_conv_packed_size": (c_size_t, [c_int, c_int, c_int]),
+    "mdtile_conv_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "mdtile_conv2d": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                              c_int, c_int, c_void_p]),
+    "mdtile_vae_attn_ws_size": (c_size_t, [c_int, c_int, c_int]),
+    "mdtile_vae_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "mdtile_crop_store": (c_int, [c_void_p, c_int, c_int, c_int, c_int, _IP, _IP, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "mdtile_vae_fast_size": (c_int, [c_int, c_int, c_int, _IP, _IP]),
+    "mdtile_vae_fast_ws_size": (c_size_t, [c_int]),
+    "mdtile_vae_fast_input": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load libmdtile.so (once).  Raises loudly when it is absent -- there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MdtileError(f"{LIB_PATH} not found: build it with `python -m mdtile.build` (hipcc, gfx950). "
+                          "This extension has no CPU/eager fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError if the library does not export what the header declares
+        fn.restype, fn.argtypes = res, args
+    if L.mdtile_version() != 100:
+        raise MdtileError(f"libmdtile.so version {L.mdtile_version()} != binding version 100")
+    _lib = L
+    return L
+
+
+def exported_symbols() -> List[str]:
+    return list(_SIGNATURES)
+
+
+def _check(rc: int, what: str):
+    if rc != OK:
+        raise MdtileError(f"{what} failed (rc={rc}): {lib().mdtile_last_error().decode(errors='replace')}")
+
+
+def _dev_tensor(t: torch.Tensor, name: str, dtype=None) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a tensor")
+    if t.device.type != "cuda":
+        raise MdtileError(f"{name} lives on {t.device}; the mdtile engine only runs on the GPU (no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise MdtileError(f"{name} has dtype {t.dtype}, expected {dtype}")
+    if not t.is_contiguous():
+        raise MdtileError(f"{name} must be contiguous")
+    return t
+
+
+def _p(t: Optional[torch.Tensor]) -> c_void_p:
+    return c_void_p(0) if t is None else c_void_p(t.data_ptr())
+
+
+def _stream() -> c_void_p:
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    try:
+        return _DTYPES[dt]
+    except KeyError:
+        raise MdtileError(f"unsupported dtype {dt}") from None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+class Plan:
+    """Grid plan == split_bboxes + init_grid_bbox (tile_utils/utils.py:160-177, abstractdiffusion.py:173-186)."""
+
+    def __init__(self, w: int, h: int, tile_w: int, tile_h: int, overlap: int, tile_bs: int, clamp: bool = True):
+        L = lib()
+        self._h = L.mdtile_plan_create(int(w), int(h), int(tile_w), int(tile_h), int(overlap), int(tile_bs), int(clamp))
+        if not self._h:
+            raise MdtileError("mdtile_plan_create: " + L.mdtile_last_error().decode(errors="replace"))
+        info = (c_int * 8)()
+        _check(L.mdtile_plan_info(self._h, info), "mdtile_plan_info")
+        (self.cols, self.rows, self.num_tiles, self.num_batches, self.tile_bs, self.tile_w, self.tile_h,
+         self.overlap) = list(info)
+        self.w, self.h = int(w), int(h)
+        buf = (c_int * (4 * self.num_tiles))()
+        _check(L.mdtile_plan_bboxes(self._h, buf), "mdtile_plan_bboxes")
+        flat = list(buf)
+        self.bboxes = [tuple(flat[4 * i:4 * i + 4]) for i in range(self.num_tiles)]  # (x, y, w, h), upstream order
+        self.batches = [self.bboxes[i * self.tile_bs:(i + 1) * self.tile_bs] for i in range(self.num_batches)]
+
+    @property
+    def handle(self):
+        return self._h
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.mdtile_plan_destroy(h)
+
+
+# ---- maps ------------------------------------------------------------------------------------------------------------
+def gaussian_weights(tile_w: int, tile_h: int, device) -> torch.Tensor:
+    out = torch.empty((tile_h, tile_w), dtype=torch.float32, device=device)
+    _dev_tensor(out, "out")
+    _check(lib().mdtile_gaussian_weights(tile_w, tile_h, _p(out), _stream()), "mdtile_gaussian_weights")
+    return out
+
+
+def feather_mask(w: int, h: int, ratio: float, device) -> torch.Tensor:
+    out = torch.empty((h, w), dtype=torch.float32, device=device)
+    _dev_tensor(out, "out")
+    _check(lib().mdtile_feather_mask(w, h, float(ratio), _p(out), _stream()), "mdtile_feather_mask")
+    return out
+
+
+def weight_map_add_grid(plan: Plan, tile_w: Optional[torch.Tensor], weights: torch.Tensor) -> None:
+    _dev_tensor(weights, "weights", torch.float32)
+    if tile_w is not None:
+        _dev_tensor(tile_w, "tile_w", torch.float32)
+        assert tuple(tile_w.shape[-2:]) == (plan.tile_h, plan.tile_w)
+    assert weights.numel() == plan.w * plan.h
+    _check(lib().mdtile_weight_map_add_grid(plan.handle, _p(tile_w), _p(weights), _stream()), "mdtile_weight_map_add_grid")
+
+
+def weight_map_add_rect(weights: torch.Tensor, x: int, y: int, w: int, h: int, rect_w: Optional[torch.Tensor] = None,
+                        scalar: float = 1.0) -> None:
+    _dev_tensor(weights, "weights", torch.float32)
+    H, W = weights.shape[-2:]
+    if rect_w is not None:
+        _dev_tensor(rect_w, "rect_w", torch.float32)
+        assert rect_w.numel() == w * h
+    _check(lib().mdtile_weight_map_add_rect(_p(weights), W, H, x, y, w, h, _p(rect_w), scalar, _stream()),
+           "mdtile_weight_map_add_rect")
+
+
+def reciprocal(x: torch.Tensor) -> torch.Tensor:
+    _dev_tensor(x, "x", torch.float32)
+    out = torch.empty_like(x)
+    _check(lib().mdtile_reciprocal(_p(x), _p(out), x.numel(), _stream()), "mdtile_reciprocal")
+    return out
+
+
+def rect_mul_canvas(rect_w: torch.Tensor, canvas: torch.Tensor, x: int, y: int, w: int, h: int) -> None:
+    _dev_tensor(rect_w, "rect_w", torch.float32)
+    _dev_tensor(canvas, "canvas", torch.float32)
+    H, W = canvas.shape[-2:]
+    assert rect_w.numel() == w * h
+    _check(lib().mdtile_rect_mul_canvas(_p(rect_w), _p(canvas), W, H, x, y, w, h, _stream()), "mdtile_rect_mul_canvas")
+
+
+# ---- gather ----------------------------------------------------------------------------------------------------------
+def gather(plan: Plan, x_in: torch.Tensor, batch_id: int) -> torch.Tensor:
+    """x_tile = cat([x_in[bbox.slicer] for bbox in batch]) -- tile-major (multidiffusion.py:155)."""
+    _dev_tensor(x_in, "x_in")
+    N, C, H, W = x_in.shape
+    assert (H, W) == (plan.h, plan.w)
+    nb = len(plan.batches[batch_id])
+    out = torch.empty((nb * N, C, plan.tile_h, plan.tile_w), dtype=x_in.dtype, device=x_in.device)
+    _check(lib().mdtile_gather(plan.handle, dtype_code(x_in.dtype), N, C, _p(x_in), batch_id, _p(out), _stream()), "mdtile_gather")
+    return out
+
+
+def gather_all(plan: Plan, x_in: torch.Tensor, out: Optional[Sequence[torch.Tensor]] = None) -> List[torch.Tensor]:
+    """All tile batches in one launch."""
+    _dev_tensor(x_in, "x_in")
+    N, C, H, W = x_in.shape
+    assert (H, W) == (plan.h, plan.w)
+    if out is None:
+        out = [torch.empty((len(b) * N, C, plan.tile_h, plan.tile_w), dtype=x_in.dtype, device=x_in.device)
+               for b in plan.batches]
+    ptrs = (c_void_p * len(out))(*[t.data_ptr() for t in out])
+    _check(lib().mdtile_gather_all(plan.handle, dtype_code(x_in.dtype), N, C, _p(x_in), ptrs, len(out), _stream()),
+           "mdtile_gather_all")
+    return list(out)
+
+
+def gather_range(plan: Plan, x_in: torch.Tensor, packed: torch.Tensor, tile_lo: int, tile_hi: int) -> torch.Tensor:
+    """Tiles [tile_lo, tile_hi) into the packed [T*N, C, th, tw] buffer (rows of other tiles are left untouched)."""
+    _dev_tensor(x_in, "x_in")
+    _dev_tensor(packed, "packed", x_in.dtype)
+    N, C, H, W = x_in.shape
+    assert (H, W) == (plan.h, plan.w) and packed.numel() == plan.num_tiles * N * C * plan.tile_h * plan.tile_w
+    _check(lib().mdtile_gather_range(plan.handle, dtype_code(x_in.dtype), N, C, _p(x_in), _p(packed), tile_lo, tile_hi, _stream()),
+           "mdtile_gather_range")
+    return packed
+
+
+def gather_rect(x_in: torch.Tensor, x: int, y: int, w: int, h: int) -> torch.Tensor:
+    _dev_tensor(x_in, "x_in")
+    N, C, H, W = x_in.shape
+    out = torch.empty((N, C, h, w), dtype=x_in.dtype, device=x_in.device)
+    _check(lib().mdtile_gather_rect(dtype_code(x_in.dtype), N, C, W, H, _p(x_in), x, y, w, h, _p(out), _stream()),
+           "mdtile_gather_rect")
+    return out
+
+
+# ---- blend -----------------------------------------------------------------------------------------------------------
+class RegionSpec:
+    """One custom region for the blend: rect, mode, its model output and (optional) weight / feather map."""
+
+    __slots__ = ("x", "y", "w", "h", "mode", "out", "weight")
+
+    def __init__(self, x, y, w, h, mode, out, weight=None):
+        self.x, self.y, self.w, self.h, self.mode, self.out, self.weight = x, y, w, h, mode, out, weight
+
+
+def _regions_array(regions: Sequence[RegionSpec], dtype):
+    if len(regions) > MAX_REGIONS:
+        raise MdtileError(f"{len(regions)} regions > {MAX_REGIONS}")
+    arr = (_Region * max(1, len(regions)))()
+    keep = []
+    for i, r in enumerate(regions):
+        out = _dev_tensor(r.out, f"region[{i}].out", dtype)
+        keep.append(out)
+        wp = 0
+        if r.weight is not None:
+            wt = _dev_tensor(r.weight, f"region[{i}].weight", torch.float32)
+            assert wt.numel() == r.w * r.h
+            keep.append(wt)
+            wp = wt.data_ptr()
+        assert tuple(out.shape[-2:]) == (r.h, r.w), f"region[{i}] output {tuple(out.shape)} vs rect {r.h}x{r.w}"
+        arr[i] = _Region(r.x, r.y, r.w, r.h, r.mode, 0, out.data_ptr(), wp)
+    return arr, keep
+
+
+def blend(plan: Plan, method: int, batch_out: Sequence[torch.Tensor], N: int, C: int, *, weights=None, tile_w=None,
+          rescale=None, regions: Sequence[RegionSpec] = (), out: Optional[torch.Tensor] = None, dtype=None, device=None,
+          partial: bool = False, tile_range=None, row_range=None, packed: bool = False) -> torch.Tensor:
+    """One fused launch replacing the scatter/normalise/feather op sequence of sample_one_step / apply_model_hijack."""
+    if len(batch_out):
+        dtype = batch_out[0].dtype
+        device = batch_out[0].device
+    elif len(regions):
+        dtype, device = regions[0].out.dtype, regions[0].out.device
+    assert dtype is not None and device is not None
+    for i, t in enumerate(batch_out):
+        _dev_tensor(t, f"batch_out[{i}]", dtype)
+    flags = 0
+    if partial:
+        flags |= BLEND_PARTIAL
+    if packed:
+        flags |= BLEND_PACKED
+    if tile_range is not None:
+        flags |= BLEND_TILE_RANGE
+    if out is None:
+        out = torch.empty((N, C, plan.h, plan.w), dtype=torch.float32 if partial else dtype, device=device)
+    _dev_tensor(out, "out", torch.float32 if partial else dtype)
+    for nm, t in (("weights", weights), ("tile_w", tile_w), ("rescale", rescale)):
+        if t is not None:
+            _dev_tensor(t, nm, torch.float32)
+    a = _BlendArgs(method, dtype_code(dtype), N, C, flags, *(tile_range or (0, 0)), *(row_range or (0, 0)),
+                   _p(weights).value, _p(tile_w).value, _p(rescale).value, out.data_ptr())
+    ptrs = (c_void_p * max(1, len(batch_out)))(*[t.data_ptr() for t in batch_out])
+    rarr, _keep = _regions_array(regions, dtype)
+    _check(lib().mdtile_blend(plan.handle, ctypes.byref(a), ptrs, len(batch_out), rarr, len(regions), _stream()), "mdtile_blend")
+    return out
+
+
+def blend_finalize(plan: Plan, method: int, partial: torch.Tensor, *, weights=None, regions: Sequence[RegionSpec] = (),
+                   out: Optional[torch.Tensor] = None, dtype=torch.float32, row_range=None) -> torch.Tensor:
+    _dev_tensor(partial, "partial", torch.float32)
+    N, C = partial.shape[:2]
+    if out is None:
+        out = torch.empty((N, C, plan.h, plan.w), dtype=dtype, device=partial.device)
+    _dev_tensor(out, "out", dtype)
+    a = _BlendArgs(method, dtype_code(dtype), N, C, 0, 0, 0, *(row_range or (0, 0)), _p(weights).value, 0, 0, out.data_ptr())
+    rarr, _keep = _regions_array(regions, dtype)
+    _check(lib().mdtile_blend_finalize(plan.handle, ctypes.byref(a), _p(partial), rarr, len(regions), _stream()),
+           "mdtile_blend_finalize")
+    return out
+
+
+# ---- tiled VAE -------------------------------------------------------------------------------------------------------
+def vae_split_tiles(h: int, w: int, tile_size: int, is_decoder: bool = True):
+    """split_tiles (scripts/tilevae.py:405-462): ([x1,x2,y1,y2] input bboxes, output bboxes).  Host ints only."""
+    L = lib()
+    n = L.mdtile_vae_split_tiles(h, w, tile_size, int(is_decoder), None, None, 0)
+    if n < 0:
+        _check(n, "mdtile_vae_split_tiles")
+    ins, outs = (c_int * (4 * n))(), (c_int * (4 * n))()
+    rc = L.mdtile_vae_split_tiles(h, w, tile_size, int(is_decoder), ins, outs, n)
+    if rc < 0:
+        _check(rc, "mdtile_vae_split_tiles")
+    fi, fo = list(ins), list(outs)
+    return [fi[4 * i:4 * i + 4] for i in range(n)], [fo[4 * i:4 * i + 4] for i in range(n)]
+
+
+def gn_stats(x: torch.Tensor, groups: int = 32):
+    """get_var_mean (tilevae.py:207-215) -> (var, mean), each [B*groups]."""
+    _dev_tensor(x, "x", torch.float32)
+    B, C = x.shape[:2]
+    HW = x.numel() // (B * C)
+    mean = torch.empty(B * groups, dtype=torch.float32, device=x.device)
+    var = torch.empty_like(mean)
+    ws = torch.empty(lib().mdtile_gn_stats_ws_size(B, groups) // 8, dtype=torch.float64, device=x.device)
+    _check(lib().mdtile_gn_stats(_p(x), B, C, HW, groups, _p(mean), _p(var), _p(ws), _stream()), "mdtile_gn_stats")
+    return var, mean
+
+
+def gn_pool(means: torch.Tensor, vars_: torch.Tensor, pixels: Sequence[int]):
+    """GroupNormParam.summary (tilevae.py:320-335) -> (var, mean)."""
+    _dev_tensor(means, "means", torch.float32)
+    _dev_tensor(vars_, "vars", torch.float32)
+    T, BG = means.shape
+    assert len(pixels) == T
+    mean = torch.empty(BG, dtype=torch.float32, device=means.device)
+    var = torch.empty_like(mean)
+    # p_i exactly as upstream forms them (fp32, tilevae.py:328-331); T host floats -- control data, not tensor math
+    px = torch.tensor([int(p) for p in pixels], dtype=torch.float32) / max(pixels)
+    frac = (px / torch.sum(px)).to(means.device)
+    _check(lib().mdtile_gn_pool(_p(means), _p(vars_), _p(frac), T, BG, _p(mean), _p(var), _stream()), "mdtile_gn_pool")
+    return var, mean
+
+
+def gn_apply(x: torch.Tensor, mean: torch.Tensor, var: torch.Tensor, gamma=None, beta=None, groups: int = 32,
+             eps: float = 1e-6, silu: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """custom_group_norm (+ fused SiLU) (tilevae.py:218-245, 102-104)."""
+    _dev_tensor(x, "x", torch.float32)
+    B, C = x.shape[:2]
+    HW = x.numel() // (B * C)
+    if out is None:
+        out = torch.empty_like(x)
+    for nm, t in (("mean", mean), ("var", var)):
+        _dev_tensor(t, nm, torch.float32)
+        assert t.numel() == B * groups
+    for nm, t in (("gamma", gamma), ("beta", beta)):
+        if t is not None:
+            _dev_tensor(t, nm, torch.float32)
+            assert t.numel() == C
+    _check(lib().mdtile_gn_apply(_p(x), _p(out), B, C, HW, groups, _p(mean), _p(var), _p(gamma), _p(beta), eps, int(silu),
+                                 _stream()), "mdtile_gn_apply")
+    return out
+
+
+def silu(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _dev_tensor(x, "x", torch.float32)
+    out = torch.empty_like(x) if out is None else out
+    _check(lib().mdtile_silu(_p(x), _p(out), x.numel(), _stream()), "mdtile_silu")
+    return out
+
+
+def add(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _dev_tensor(a, "a", torch.float32)
+    _dev_tensor(b, "b", torch.float32)
+    assert a.shape == b.shape
+    out = torch.empty_like(a) if out is None else out
+    _check(lib().mdtile_add(_p(a), _p(b), _p(out), a.numel(), _stream()), "mdtile_add")
+    return out
+
+
+class PackedConv:
+    """Weights of one nn.Conv2d (1x1 or 3x3, stride 1, 'same' padding) re-laid out once for the MFMA conv kernel."""
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor]):
+        _dev_tensor(weight, "weight", torch.float32)
+        self.cout, self.cin, kh, kw = weight.shape
+        assert kh == kw and kh in (1, 3)
+        self.ksize = kh
+        n = lib().mdtile_conv_packed_size(self.cout, self.cin, self.ksize)
+        self.packed = torch.empty(n, dtype=torch.float32, device=weight.device)
+        _check(lib().mdtile_conv_pack(_p(weight), _p(self.packed), self.cout, self.cin, self.ksize, _stream()), "mdtile_conv_pack")
+        self.bias = None if bias is None else _dev_tensor(bias.detach().contiguous(), "bias", torch.float32)
+
+    def __call__(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, upsample2x: bool = False,
+                 token_major: bool = False) -> torch.Tensor:
+        _dev_tensor(x, "x", torch.float32)
+        B, cin, H, W = x.shape
+        assert cin == self.cin, f"conv expects {self.cin} input channels, got {cin}"
+        if upsample2x:
+            H, W = 2 * H, 2 * W
+        shape = (B, H * W, self.cout) if token_major else (B, self.cout, H, W)
+        y = torch.empty(shape, dtype=torch.float32, device=x.device)
+        if residual is not None:
+            _dev_tensor(residual, "residual", torch.float32)
+            assert residual.shape == y.shape
+        _check(lib().mdtile_conv2d(_p(x), _p(self.packed), _p(self.bias), _p(residual), _p(y), B, self.cin, self.cout, H, W,
+                                   self.ksize, CONV_UPSAMPLE2X if upsample2x else 0, int(token_major), _stream()), "mdtile_conv2d")
+        return y
+
+
+def vae_attn(q: torch.Tensor, k: torch.Tensor, v_tok: torch.Tensor, scale: float) -> torch.Tensor:
+    """Single-head attention core (tile_utils/attn.py:55-70).  q,k: [B,C,T]; v_tok: [B,T,C]; returns [B,C,T]."""
+    _dev_tensor(q, "q", torch.float32)
+    _dev_tensor(k, "k", torch.float32)
+    _dev_tensor(v_tok, "v", torch.float32)
+    B, C, T = q.shape
+    assert k.shape == q.shape and tuple(v_tok.shape) == (B, T, C)
+    out = torch.empty_like(q)
+    ws_bytes = lib().mdtile_vae_attn_ws_size(B, C, T)
+    ws = torch.empty(max(1, (ws_bytes + 3) // 4), dtype=torch.float32, device=q.device)
+    _check(lib().mdtile_vae_attn(_p(q), _p(k), _p(v_tok), _p(out), B, C, T, scale, _p(ws), _stream()), "mdtile_vae_attn")
+    return out
+
+
+def crop_store(tile: torch.Tensor, in_bbox, out_bbox, result: torch.Tensor, is_decoder: bool = True) -> None:
+    """result[..., out_bbox] = crop_valid_region(tile) (tilevae.py:248-259, 630-632)."""
+    _dev_tensor(tile, "tile", torch.float32)
+    _dev_tensor(result, "result", torch.float32)
+    N, C, th, tw = tile.shape
+    assert result.shape[:2] == (N, C)
+    ib, ob = (c_int * 4)(*in_bbox), (c_int * 4)(*out_bbox)
+    _check(lib().mdtile_crop_store(_p(tile), N, C, th, tw, ib, ob, int(is_decoder), _p(result), result.shape[2], result.shape[3],
+                                   _stream()), "mdtile_crop_store")
+
+
+def vae_fast_input(z: torch.Tensor, tile_size: int) -> torch.Tensor:
+    """Fast-mode estimator input (tilevae.py:545-559): downsample to <= tile_size, re-standardise, clamp."""
+    _dev_tensor(z, "z", torch.float32)
+    N, C, H, W = z.shape
+    oh, ow = c_int(), c_int()
+    _check(lib().mdtile_vae_fast_size(H, W, int(tile_size), ctypes.byref(oh), ctypes.byref(ow)), "mdtile_vae_fast_size")
+    out = torch.empty((N, C, oh.value, ow.value), dtype=torch.float32, device=z.device)
+    ws = torch.empty((lib().mdtile_vae_fast_ws_size(C) + 7) // 8, dtype=torch.float64, device=z.device)
+    _check(lib().mdtile_vae_fast_input(_p(z), N, C, H, W, int(tile_size), _p(out), _p(ws), _stream()), "mdtile_vae_fast_input")
+    return out

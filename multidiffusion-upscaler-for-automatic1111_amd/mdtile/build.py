@@ -1,0 +1,82 @@
+"""Builds libmdtile.so (all HIP kernels + the C ABI) in-tree with hipcc for gfx950.
+
+    python -m mdtile.build          (from the extension root)   or   __graft_entry__.build()
+
+The .so is git-ignored but travels with the working tree (A1111 extension dir / gpurun snapshot).
+"""
+from __future__ import annotations
+
+import glob
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EXT_ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(EXT_ROOT, "csrc")
+INCLUDE = os.path.join(os.path.dirname(EXT_ROOT), "include")
+LIB = os.path.join(HERE, "libmdtile.so")
+STAMP = os.path.join(HERE, ".libmdtile.stamp")
+
+# -ffp-contract=off: the blend reproduces eager-torch op-by-op fp32 rounding (see csrc/blend.hip); kernels that
+# want FMAs ask for them explicitly (fmaf / MFMA builtins).
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+               "-Wall", "-Wno-unused-function"]
+
+
+def _sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _digest() -> str:
+    h = hashlib.sha256()
+    for f in _sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(INCLUDE, "mdtile.h")]:
+        with open(f, "rb") as fh:
+            h.update(f.encode())
+            h.update(fh.read())
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    return h.hexdigest()
+
+
+def hipcc_path() -> str | None:
+    return shutil.which("hipcc") or ("/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else None)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    """Compile if sources changed; returns the path of the shared library."""
+    digest = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read().strip() == digest:
+        return LIB
+    hipcc = hipcc_path()
+    if hipcc is None:
+        raise RuntimeError("hipcc not found: libmdtile.so cannot be built (ROCm toolchain required)")
+    objs = []
+    objdir = os.path.join(EXT_ROOT, "build")
+    os.makedirs(objdir, exist_ok=True)
+    procs = []
+    for src in _sources():
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        cmd = [hipcc] + [f for f in HIPCC_FLAGS if f != "-shared"] + ["-c", src, "-o", obj]
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+        if verbose and out.strip():
+            print(out)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}")
+    with open(STAMP, "w") as f:
+        f.write(digest)
+    if verbose:
+        print(f"[mdtile] built {LIB} from {len(objs)} sources")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

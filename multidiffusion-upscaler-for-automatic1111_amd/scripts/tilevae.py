@@ -1,0 +1,418 @@
+"""
+Tiled VAE on the mdtile engine -- same plugin surface as upstream scripts/tilevae.py:
+`Script.title/show/ui/process/postprocess` with the positional argument order
+(enabled, encoder_tile_size, decoder_tile_size, vae_to_gpu, fast_decoder, fast_encoder, color_fix), and a `VAEHook`
+callable that replaces `vae.decoder.forward` (upstream :739-745).
+
+What changed underneath (MI355X-first, 288 GB HBM):
+  * the ldm Decoder is compiled ONCE into a flat program (upstream's task queue, :107-195) whose steps are mdtile C-ABI
+    calls: fp32-MFMA implicit-GEMM convs with fused residual add / nearest-2x upsample, fixed-statistics
+    GroupNorm+SiLU in one pass, a flash-style attention kernel (no T x T matrix), crop+store into the result;
+  * tiles, residuals and parked activations never leave the GPU (upstream's .cpu()/.to(device) ping-pong, :534-642,
+    exists only to fit small VRAM);
+  * GroupNorm semantics are upstream's: statistics frozen from a down-sampled latent in fast mode (:542-563, :464-505)
+    or pooled across tiles at every norm in slow mode (:320-335) -- NOT the untiled network's.
+The encoder direction is not built yet: `encoder.forward` is left untouched.
+"""
+from __future__ import annotations
+
+import math
+from time import time
+from typing import List, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+import modules.scripts as scripts
+import modules.devices as devices
+from modules.shared import state
+
+import mdtile
+
+
+def get_rcmd_enc_tsize() -> int:
+    """Upstream picks by VRAM (:79-87); every MI355X has 288 GB, i.e. the top bucket."""
+    return 3072 if torch.cuda.is_available() else 512
+
+
+def get_rcmd_dec_tsize() -> int:
+    """Upstream: 256 for > 30 GB, 64 off-GPU (:90-99)."""
+    return 256 if torch.cuda.is_available() else 64
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# program = upstream's task queue, with the fusions the engine offers already applied
+# ---------------------------------------------------------------------------------------------------------------------
+class Step:
+    __slots__ = ("kind", "conv", "norm", "silu", "attn", "fuse_res", "upsample")
+
+    def __init__(self, kind, conv=None, norm=None, silu=False, attn=None, fuse_res=False, upsample=False):
+        self.kind, self.conv, self.norm, self.silu, self.attn = kind, conv, norm, silu, attn
+        self.fuse_res, self.upsample = fuse_res, upsample
+
+
+class AttnPack:
+    """q/k/v/proj_out of one AttnBlock, packed for the engine; v is produced token-major for the PV contraction."""
+
+    def __init__(self, attn):
+        self.q, self.k, self.v, self.proj = (_pack(attn.q), _pack(attn.k), _pack(attn.v), _pack(attn.proj_out))
+        self.channels = attn.q.weight.shape[0]
+
+    def __call__(self, h: Tensor, residual: Tensor) -> Tensor:
+        B, C, H, W = h.shape
+        q = self.q(h).view(B, C, H * W)
+        k = self.k(h).view(B, C, H * W)
+        v = self.v(h, token_major=True)
+        o = mdtile.vae_attn(q, k, v, float(int(C) ** (-0.5)))          # softmax(q^T k / sqrt(C)) v   (attn.py:55-67)
+        return self.proj(o.view(B, C, H, W), residual=residual)        # proj_out + the queue's add_res
+
+
+def _pack(conv) -> mdtile.PackedConv:
+    assert conv.stride == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1, "engine convs are stride-1 dense"
+    k = conv.kernel_size[0]
+    assert conv.kernel_size == (k, k) and conv.padding == (k // 2, k // 2), f"unsupported conv {conv}"
+    return mdtile.PackedConv(conv.weight.detach().float().contiguous(),
+                             None if conv.bias is None else conv.bias.detach().float())
+
+
+def _norm_params(gn):
+    assert gn.num_groups == 32, "Tiled VAE hard-codes 32 groups (upstream tilevae.py:299)"
+    g = gn.weight.detach().float().contiguous() if getattr(gn, "weight", None) is not None else None
+    b = gn.bias.detach().float().contiguous() if getattr(gn, "bias", None) is not None else None
+    return g, b
+
+
+def _resblock(steps: List[Step], blk):
+    if blk.in_channels != blk.out_channels:
+        shortcut = blk.conv_shortcut if blk.use_conv_shortcut else blk.nin_shortcut
+        steps.append(Step("store_res", conv=_pack(shortcut)))
+    else:
+        steps.append(Step("store_res"))
+    steps.append(Step("norm", norm=_norm_params(blk.norm1), silu=True))
+    steps.append(Step("conv", conv=_pack(blk.conv1)))
+    steps.append(Step("norm", norm=_norm_params(blk.norm2), silu=True))
+    steps.append(Step("conv", conv=_pack(blk.conv2), fuse_res=True))       # conv2 + add_res in one epilogue
+
+
+def build_task_queue(net, is_decoder: bool = True) -> List[Step]:
+    """Linearise an ldm Decoder exactly in upstream's order (:139-195): conv_in, mid(res, attn, res), levels top-down
+    with num_res_blocks+1 resblocks (+ upsample except on level 0), norm_out, silu, conv_out.  30 norms for SD/SDXL."""
+    if not is_decoder:
+        raise NotImplementedError("mdtile engine: the encoder direction is not built yet")
+    steps = [Step("conv", conv=_pack(net.conv_in))]
+    _resblock(steps, net.mid.block_1)
+    steps += [Step("store_res"), Step("norm", norm=_norm_params(net.mid.attn_1.norm)),
+              Step("attn", attn=AttnPack(net.mid.attn_1))]
+    _resblock(steps, net.mid.block_2)
+    for lvl in reversed(range(net.num_resolutions)):
+        for i in range(net.num_res_blocks + 1):
+            _resblock(steps, net.up[lvl].block[i])
+        if lvl != 0:
+            steps.append(Step("conv", conv=_pack(net.up[lvl].upsample.conv), upsample=True))  # nearest-2x fused
+    if not net.give_pre_end:
+        steps.append(Step("norm", norm=_norm_params(net.norm_out), silu=True))
+        steps.append(Step("conv", conv=_pack(net.conv_out)))
+        if net.tanh_out:
+            steps.append(Step("tanh"))
+    return steps
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GroupNorm statistics (upstream :207-245, :289-361)
+# ---------------------------------------------------------------------------------------------------------------------
+def get_var_mean(input: Tensor, num_groups: int, eps: float = 1e-6) -> Tuple[Tensor, Tensor]:
+    return mdtile.gn_stats(input, num_groups)
+
+
+def custom_group_norm(input, num_groups, mean, var, weight=None, bias=None, eps=1e-6, silu: bool = False):
+    return mdtile.gn_apply(input, mean, var, weight, bias, num_groups, eps, silu)
+
+
+def crop_valid_region(x, input_bbox, target_bbox, is_decoder):
+    padded = [i * 8 if is_decoder else i // 8 for i in input_bbox]
+    m = [target_bbox[i] - padded[i] for i in range(4)]
+    return x[:, :, m[2]:x.size(2) + m[3], m[0]:x.size(3) + m[1]]
+
+
+class GroupNormParam:
+    """Slow-mode collector: per-tile (var, mean) rows pooled by pixel count (upstream :289-335)."""
+
+    def __init__(self):
+        self.var_list, self.mean_list, self.pixel_list = [], [], []
+
+    def add_tile(self, tile: Tensor):
+        var, mean = get_var_mean(tile, 32)
+        self.var_list.append(var)
+        self.mean_list.append(mean)
+        self.pixel_list.append(tile.shape[2] * tile.shape[3])
+
+    def summary(self) -> Optional[Tuple[Tensor, Tensor]]:
+        if not self.var_list:
+            return None
+        return mdtile.gn_pool(torch.vstack(self.mean_list), torch.vstack(self.var_list), self.pixel_list)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+class TileState:
+    __slots__ = ("x", "res", "pc")
+
+    def __init__(self, x):
+        self.x, self.res, self.pc = x, [], 0
+
+
+class VAEHook:
+
+    def __init__(self, net, tile_size, is_decoder: bool, fast_decoder: bool, fast_encoder: bool, color_fix: bool,
+                 to_gpu: bool = False):
+        self.net = net
+        self.tile_size = tile_size
+        self.is_decoder = is_decoder
+        self.fast_mode = (fast_encoder and not is_decoder) or (fast_decoder and is_decoder)
+        self.color_fix = color_fix and not is_decoder
+        self.to_gpu = to_gpu
+        self.pad = 11 if is_decoder else 32
+        self._program: Optional[List[Step]] = None
+        self.last_seconds = None
+        self.shard = (0, 1)   # (rank, world): multi-GPU runs decode tiles rank, rank+world, ... (mdtile/sharding.py)
+
+    def __call__(self, x):
+        original_device = next(self.net.parameters()).device
+        try:
+            if self.to_gpu:
+                self.net = self.net.to(devices.get_optimal_device())
+            B, C, H, W = x.shape
+            if max(H, W) <= self.pad * 2 + self.tile_size:
+                print("[Tiled VAE]: the input size is tiny and unnecessary to tile.")
+                return self.net.original_forward(x)
+            return self.vae_tile_forward(x)
+        finally:
+            self.net = self.net.to(original_device)
+
+    # ---- geometry (host ints via the C ABI) -------------------------------------------------------------------------
+    def get_best_tile_size(self, lowerbound, upperbound):
+        divider = 32
+        while divider >= 2:
+            rem = lowerbound % divider
+            if rem == 0:
+                return lowerbound
+            cand = lowerbound - rem + divider
+            if cand <= upperbound:
+                return cand
+            divider //= 2
+        return lowerbound
+
+    def split_tiles(self, h, w):
+        return mdtile.vae_split_tiles(h, w, self.tile_size, self.is_decoder)
+
+    # ---- program ------------------------------------------------------------------------------------------------------
+    def program(self) -> List[Step]:
+        dev = next(self.net.parameters()).device
+        if self._program is None or self._program_dev != dev:
+            self._program = build_task_queue(self.net, self.is_decoder)
+            self._program_dev = dev
+        return self._program
+
+    @staticmethod
+    def _run_until_norm(steps: List[Step], st: TileState):
+        """Advance one tile to its next GroupNorm (exclusive) or to the end."""
+        while st.pc < len(steps):
+            s = steps[st.pc]
+            if s.kind == "norm":
+                return
+            if s.kind == "store_res":
+                st.res.append(st.x if s.conv is None else s.conv(st.x))
+            elif s.kind == "conv":
+                st.x = s.conv(st.x, residual=st.res.pop() if s.fuse_res else None, upsample2x=s.upsample)
+            elif s.kind == "attn":
+                st.x = s.attn(st.x, st.res.pop())
+            elif s.kind == "tanh":
+                st.x = torch.tanh(st.x)
+            st.pc += 1
+
+    @staticmethod
+    def _apply_norm(steps: List[Step], st: TileState, var: Tensor, mean: Tensor):
+        s = steps[st.pc]
+        gamma, beta = s.norm
+        keep = st.res and st.res[-1] is st.x          # identity shortcut: the residual aliases the pre-norm tensor
+        st.x = mdtile.gn_apply(st.x, mean, var, gamma, beta, 32, 1e-6, s.silu, out=None if keep else st.x)
+        st.pc += 1
+
+    @torch.no_grad()
+    def estimate_group_norm(self, z: Tensor, steps: List[Step]) -> Optional[List[Tuple[Tensor, Tensor]]]:
+        """Fast mode: run the program on the down-sampled latent and freeze (var, mean) at every norm (:464-505).
+        Returns None (-> slow mode) if a NaN shows up, as upstream."""
+        st = TileState(z)
+        frozen = []
+        n_norm = sum(1 for s in steps if s.kind == "norm")
+        while True:
+            self._run_until_norm(steps, st)
+            if st.pc >= len(steps):
+                break
+            var, mean = get_var_mean(st.x, 32)
+            frozen.append((var, mean))
+            if len(frozen) == n_norm:
+                break
+            self._apply_norm(steps, st, var, mean)
+            if torch.isnan(st.x).any().item():
+                print("Nan detected in fast mode estimation. Fast mode disabled.")
+                return None
+        return frozen
+
+    def _pooled_across_ranks(self, gp: "GroupNormParam", steps, dev):
+        """Slow mode on several GPUs: all-reduce(sum) of [sum px*mean, sum px*var, sum px] (2*B*32+1 floats) per barrier."""
+        import torch.distributed as dist
+        from mdtile import sharding
+        flag = torch.tensor([1.0 if gp.var_list else 0.0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if flag.item() == 0.0:
+            return None
+        BG = None
+        if gp.var_list:
+            px = torch.tensor(gp.pixel_list, dtype=torch.float32, device=dev).unsqueeze(1)
+            sm, sv, sp = (torch.vstack(gp.mean_list) * px).sum(0), (torch.vstack(gp.var_list) * px).sum(0), px.sum().view(1)
+            BG = sm.numel()
+        shape = torch.tensor([BG or 0], device=dev)
+        dist.all_reduce(shape, op=dist.ReduceOp.MAX)
+        if BG is None:
+            BG = int(shape.item())
+            sm, sv, sp = torch.zeros(BG, device=dev), torch.zeros(BG, device=dev), torch.zeros(1, device=dev)
+        return sharding.allreduce_stats(sm, sv, sp)
+
+    @torch.no_grad()
+    def vae_tile_forward(self, z: Tensor) -> Tensor:
+        t0 = time()
+        net = self.net
+        dev = next(net.parameters()).device
+        dtype = next(net.parameters()).dtype
+        if dev.type != "cuda":
+            raise mdtile.MdtileError("Tiled VAE (mdtile engine) needs the VAE on the GPU; enable 'Move VAE to GPU'")
+        z = z.detach().to(device=dev, dtype=torch.float32).contiguous()
+        N, _, height, width = z.shape
+        net.last_z_shape = z.shape
+        print(f"[Tiled VAE]: input_size: {z.shape}, tile_size: {self.tile_size}, padding: {self.pad}")
+        in_bboxes, out_bboxes = self.split_tiles(height, width)
+        steps = self.program()
+
+        frozen = None
+        if self.fast_mode:
+            zs = mdtile.vae_fast_input(z, self.tile_size)
+            print(f"[Tiled VAE]: Fast mode enabled, estimating group norm parameters on {zs.shape[3]} x {zs.shape[2]} image")
+            frozen = self.estimate_group_norm(zs, steps)
+
+        rank, world = self.shard
+        mine = list(range(len(in_bboxes))) if world == 1 else list(range(rank, len(in_bboxes), world))
+        tiles = {i: TileState(mdtile.gather_rect(z, b[0], b[2], b[1] - b[0], b[3] - b[2])) for i, b in enumerate(in_bboxes) if i in set(mine)}
+        result = None
+        interrupted = False
+
+        def finish(i: int):
+            nonlocal result
+            x = tiles[i].x
+            if result is None:
+                result = torch.zeros((N, x.shape[1], height * 8, width * 8), device=dev, dtype=torch.float32)
+            devices.test_for_nans(x, "vae")
+            mdtile.crop_store(x, in_bboxes[i], out_bboxes[i], result, self.is_decoder)
+            tiles[i] = None
+
+        if frozen is not None:
+            # every norm is already resolved: each tile runs start to finish on its own (upstream: one sweep)
+            for i in mine:
+                if state.interrupted:
+                    interrupted = True
+                    break
+                st, k = tiles[i], 0
+                while True:
+                    self._run_until_norm(steps, st)
+                    if st.pc >= len(steps):
+                        break
+                    self._apply_norm(steps, st, *frozen[k])
+                    k += 1
+                finish(i)
+        else:
+            # slow mode: all tiles advance in lockstep from norm to norm; statistics pooled over tiles at each one
+            forward = True
+            while not interrupted:
+                gp = GroupNormParam()
+                for i in (mine if forward else reversed(mine)):
+                    if state.interrupted:
+                        interrupted = True
+                        break
+                    self._run_until_norm(steps, tiles[i])
+                    if tiles[i].pc < len(steps):
+                        gp.add_tile(tiles[i].x)
+                if interrupted:
+                    break
+                pooled = gp.summary() if world == 1 else self._pooled_across_ranks(gp, steps, z.device)
+                if pooled is None:
+                    for i in mine:
+                        finish(i)
+                    break
+                for i in mine:
+                    self._apply_norm(steps, tiles[i], *pooled)
+                forward = not forward
+
+        self.last_seconds = time() - t0
+        if interrupted or result is None:
+            from modules.sd_vae_approx import cheap_approximation
+            approx = torch.cat([torch.nn.functional.interpolate(cheap_approximation(x).unsqueeze(0), scale_factor=8,
+                                                                mode="nearest-exact") for x in z], dim=0)
+            return approx.to(dev, dtype=dtype)
+        torch.cuda.synchronize(dev)
+        print(f"[Tiled VAE]: Done in {time() - t0:.3f}s, max VRAM alloc {torch.cuda.max_memory_allocated(dev) / 2**20:.3f} MB")
+        return result.to(dtype)
+
+
+class Script(scripts.Script):
+
+    def __init__(self):
+        self.hooked = False
+
+    def title(self):
+        return "Tiled VAE"
+
+    def show(self, is_img2img):
+        return scripts.AlwaysVisible
+
+    def ui(self, is_img2img):
+        import gradio as gr
+        tab = "t2i" if not is_img2img else "i2i"
+        uid = lambda name: f"MD-{tab}-{name}"  # noqa: E731
+        with gr.Accordion("Tiled VAE", open=False, elem_id=f"MDV-{tab}"):
+            with gr.Row():
+                enabled = gr.Checkbox(label="Enable Tiled VAE", value=False, elem_id=uid("enable"))
+                vae_to_gpu = gr.Checkbox(label="Move VAE to GPU (if possible)", value=True, elem_id=uid("vae2gpu"))
+            with gr.Row():
+                encoder_tile_size = gr.Slider(label="Encoder Tile Size", minimum=256, maximum=4096, step=16,
+                                              value=get_rcmd_enc_tsize(), elem_id=uid("enc-size"))
+                decoder_tile_size = gr.Slider(label="Decoder Tile Size", minimum=48, maximum=512, step=16,
+                                              value=get_rcmd_dec_tsize(), elem_id=uid("dec-size"))
+            with gr.Row():
+                fast_encoder = gr.Checkbox(label="Fast Encoder", value=True, elem_id=uid("fastenc"))
+                color_fix = gr.Checkbox(label="Fast Encoder Color Fix", value=False, elem_id=uid("fastenc-colorfix"))
+                fast_decoder = gr.Checkbox(label="Fast Decoder", value=True, elem_id=uid("fastdec"))
+        return [enabled, encoder_tile_size, decoder_tile_size, vae_to_gpu, fast_decoder, fast_encoder, color_fix]
+
+    def process(self, p, enabled: bool, encoder_tile_size: int, decoder_tile_size: int, vae_to_gpu: bool,
+                fast_decoder: bool, fast_encoder: bool, color_fix: bool):
+        vae = p.sd_model.first_stage_model
+        decoder = vae.decoder
+        if not enabled:
+            if self.hooked and isinstance(decoder.forward, VAEHook):
+                decoder.forward.net = None
+                decoder.forward = decoder.original_forward
+            self.hooked = False
+            return
+        if not hasattr(decoder, "original_forward"):
+            decoder.original_forward = decoder.forward
+        self.hooked = True
+        decoder.forward = VAEHook(decoder, decoder_tile_size, is_decoder=True, fast_decoder=fast_decoder,
+                                  fast_encoder=fast_encoder, color_fix=color_fix, to_gpu=vae_to_gpu)
+        # encoder.forward is intentionally left alone until the encode direction lands in the engine
+
+    def postprocess(self, p, processed, enabled: bool, *args):
+        if not enabled:
+            return
+        decoder = p.sd_model.first_stage_model.decoder
+        if isinstance(decoder.forward, VAEHook):
+            decoder.forward.net = None
+            decoder.forward = decoder.original_forward

@@ -1,0 +1,201 @@
+"""GPU parity of the Tiled-VAE kernels (GroupNorm statistics / apply+SiLU, MFMA conv, flash attention, crop+store, fast-mode
+input) and of the whole tiled decode through the plugin's VAEHook, against the oracle and the upstream-generated goldens.
+Tolerances (fp32 everywhere; summation order differs from eager torch): primitives <= 2e-5 relative, end-to-end decode
+<= 1e-3 relative to the output's max (the BASELINE.json target), in practice ~1e-5."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ldm_decoder as ld
+from oracle import stub_host as sh
+from oracle import vae_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a: torch.Tensor, b: torch.Tensor) -> float:
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 9, 13), (1, 128, 33, 47), (1, 512, 20, 28), (3, 32, 5, 7), (1, 256, 64, 64)])
+def test_gn_stats_and_apply(plugin, cuda, shape):
+    E = plugin.engine
+    torch.manual_seed(11)
+    t = torch.randn(*shape) * 3 + 0.5
+    var_r, mean_r = vo.get_var_mean(t, 32)
+    var, mean = E.gn_stats(t.to(cuda), 32)
+    assert _rel(mean.cpu(), mean_r) < 1e-5 and _rel(var.cpu(), var_r) < 1e-5
+    g, b = torch.randn(shape[1]), torch.randn(shape[1])
+    for silu in (False, True):
+        ref = vo.custom_group_norm(t, 32, mean_r, var_r, g, b)
+        ref = F.silu(ref) if silu else ref
+        out = E.gn_apply(t.to(cuda), mean_r.to(cuda), var_r.to(cuda), g.to(cuda), b.to(cuda), 32, 1e-6, silu)
+        assert (out.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    out = E.gn_apply(t.to(cuda), mean_r.to(cuda), var_r.to(cuda), None, None, 32, 1e-6, False)
+    assert (out.cpu() - vo.custom_group_norm(t, 32, mean_r, var_r)).abs().max().item() < 2e-5
+
+
+def test_gn_golden(plugin, cuda, golden_vae):
+    E = plugin.engine
+    torch.manual_seed(11)
+    t = torch.randn(2, 64, 9, 13) * 3 + 0.5
+    g, b = torch.randn(64), torch.randn(64)
+    var, mean = E.gn_stats(t.to(cuda), 32)
+    assert np.allclose(var.cpu().numpy(), golden_vae["gn/var"], rtol=1e-5) and np.allclose(mean.cpu().numpy(), golden_vae["gn/mean"], rtol=1e-5, atol=1e-6)
+    out = E.gn_apply(t.to(cuda), mean, var, g.to(cuda), b.to(cuda))
+    assert np.allclose(out.cpu().numpy(), golden_vae["gn/out"], rtol=1e-4, atol=2e-5)
+
+
+def test_gn_pool_silu_add(plugin, cuda):
+    E = plugin.engine
+    torch.manual_seed(1)
+    vars_ = [torch.rand(64) + 0.1 for _ in range(5)]
+    means = [torch.randn(64) for _ in range(5)]
+    px = [86 * 86, 86 * 64, 64 * 86, 64 * 64, 70 * 70]
+    v_r, m_r = vo.pool_stats(vars_, means, px)
+    v, m = E.gn_pool(torch.vstack(means).to(cuda), torch.vstack(vars_).to(cuda), px)
+    assert _rel(v.cpu(), v_r) < 1e-6 and _rel(m.cpu(), m_r) < 1e-6
+    x = torch.randn(3, 7, 11, 13) * 4
+    y = torch.randn(3, 7, 11, 13)
+    assert (E.silu(x.to(cuda)).cpu() - F.silu(x)).abs().max().item() < 1e-6
+    assert torch.equal(E.add(x.to(cuda), y.to(cuda)).cpu(), x + y)
+
+
+CONV_CASES = [  # B, cin, cout, k, H, W, upsample, residual, token_major
+    (1, 4, 128, 3, 20, 30, False, False, False),     # conv_in shape class (cin < slab)
+    (2, 128, 128, 3, 17, 45, False, True, False),    # ragged tile edges + fused residual, batch 2
+    (1, 64, 256, 1, 19, 33, False, False, False),    # nin_shortcut
+    (1, 128, 3, 3, 24, 40, False, False, False),     # conv_out (narrow config, Cout=3)
+    (1, 32, 32, 3, 16, 32, False, True, False),      # small-decoder widths
+    (1, 96, 64, 3, 9, 70, False, False, False),
+    (1, 128, 128, 3, 32, 48, True, False, False),    # fused nearest-2x upsample
+    (1, 128, 128, 1, 13, 29, False, False, True),    # v projection, token-major output
+    (1, 512, 512, 3, 24, 40, False, True, False),    # SD mid-block width
+    (1, 512, 512, 1, 16, 24, False, False, True),
+]
+
+
+@pytest.mark.parametrize("B,cin,cout,k,H,W,up,res,tok", CONV_CASES)
+def test_conv2d_vs_torch(plugin, cuda, B, cin, cout, k, H, W, up, res, tok):
+    E = plugin.engine
+    torch.manual_seed(cin * 7 + cout + k)
+    conv = torch.nn.Conv2d(cin, cout, k, 1, k // 2)
+    hin, win = (H // 2, W // 2) if up else (H, W)
+    x = torch.randn(B, cin, hin, win)
+    with torch.no_grad():
+        ref = conv(F.interpolate(x, scale_factor=2.0, mode="nearest") if up else x)
+        r = torch.randn_like(ref) if res else None
+        if res:
+            ref = ref + r
+    pc = E.PackedConv(conv.weight.detach().to(cuda), conv.bias.detach().to(cuda))
+    rr = None
+    if res:
+        rr = (r.permute(0, 2, 3, 1).reshape(B, H * W, cout) if tok else r).contiguous().to(cuda)
+    out = pc(x.to(cuda), residual=rr, upsample2x=up, token_major=tok).cpu()
+    if tok:
+        out = out.view(B, H, W, cout).permute(0, 3, 1, 2)
+    err = _rel(out, ref)
+    assert err < 2e-5, f"conv rel err {err}; worst at {np.unravel_index((out - ref).abs().argmax().item(), ref.shape)}"
+
+
+@pytest.mark.parametrize("B,C,T", [(1, 128, 64), (1, 128, 100), (2, 128, 200), (1, 256, 77), (1, 512, 150), (1, 512, 1000)])
+def test_attention_vs_oracle(plugin, cuda, B, C, T):
+    E = plugin.engine
+    torch.manual_seed(C + T)
+    q, k, v = torch.randn(B, C, T), torch.randn(B, C, T) * 1.5, torch.randn(B, C, T)
+    scale = float(int(C) ** (-0.5))
+    w_ = torch.softmax(torch.bmm(q.permute(0, 2, 1), k) * scale, dim=2)          # attn.py:57-60
+    ref = torch.bmm(v, w_.permute(0, 2, 1))                                        # attn.py:63-66
+    out = E.vae_attn(q.to(cuda), k.to(cuda), v.permute(0, 2, 1).contiguous().to(cuda), scale).cpu()
+    err = _rel(out, ref)
+    assert err < 2e-5, f"attention rel err {err}"
+
+
+def test_attention_online_softmax_rescale_branch(plugin, cuda):
+    """Force the running-max update late in the key sequence (a spike in the last key block) -- bounded random data alone
+    never exercises a wrong rescale."""
+    E = plugin.engine
+    torch.manual_seed(0)
+    B, C, T = 1, 128, 300
+    q, k, v = torch.randn(B, C, T), torch.randn(B, C, T), torch.randn(B, C, T)
+    k[:, :, 290] = q[:, :, 5] * 4.0      # query 5 matches key 290 very strongly
+    k[:, :, 3] = q[:, :, 170] * 3.0
+    scale = float(C ** -0.5)
+    w_ = torch.softmax(torch.bmm(q.permute(0, 2, 1), k) * scale, dim=2)
+    ref = torch.bmm(v, w_.permute(0, 2, 1))
+    out = E.vae_attn(q.to(cuda), k.to(cuda), v.permute(0, 2, 1).contiguous().to(cuda), scale).cpu()
+    assert _rel(out, ref) < 2e-5
+
+
+def test_attn_block_golden(plugin, cuda, golden_vae):
+    """q/k/v/proj_out 1x1 convs + attention core == upstream attn_forward on the golden AttnBlock (C=64 is below the
+    kernel's 128-channel granule, so this one checks the convs and uses a 128-channel twin for the core)."""
+    torch.manual_seed(12)
+    ab = ld.AttnBlock(128).eval()
+    hx = torch.randn(1, 128, 7, 9)
+    with torch.no_grad():
+        ref = vo.attn_body(ab, hx)
+    pack = plugin.tilevae.AttnPack(ab.to(cuda))
+    out = pack(hx.to(cuda), torch.zeros_like(hx).to(cuda)).cpu()
+    assert _rel(out, ref) < 2e-5
+
+
+def test_crop_store_and_fast_input(plugin, cuda):
+    E = plugin.engine
+    ins, outs = vo.split_tiles(40, 56, 16)
+    result = torch.zeros(1, 3, 320, 448, device=cuda)
+    ref = torch.zeros(1, 3, 320, 448)
+    torch.manual_seed(0)
+    for ib, ob in zip(ins, outs):
+        tile = torch.randn(1, 3, (ib[3] - ib[2]) * 8, (ib[1] - ib[0]) * 8)
+        E.crop_store(tile.to(cuda), ib, ob, result)
+        ref[:, :, ob[2]:ob[3], ob[0]:ob[1]] = vo.crop_valid_region(tile, ib, ob)
+    assert torch.equal(result.cpu(), ref)
+    for (H, W, ts) in [(40, 56, 16), (128, 128, 64), (30, 70, 24), (97, 61, 32)]:
+        torch.manual_seed(H)
+        z = torch.randn(2, 4, H, W) * 1.7 + 0.3
+        got = E.vae_fast_input(z.to(cuda), ts).cpu()
+        ref = vo.fast_mode_input(z, ts)
+        assert got.shape == ref.shape
+        assert (got - ref).abs().max().item() < 1e-5
+
+
+def test_tiled_decode_vs_goldens_and_oracle(plugin, cuda, cases, golden_vae):
+    s = cases["vae_stride"]
+    for c in cases["vae"]:
+        dec = ld.make_decoder(c["dec_seed"], small=True).to(cuda)
+        dec.original_forward = dec.forward
+        torch.manual_seed(c["seed"])
+        z = torch.randn(1, 4, c["H"], c["W"])
+        hook = plugin.tilevae.VAEHook(dec, c["ts"], is_decoder=True, fast_decoder=c["fast"], fast_encoder=False, color_fix=False)
+        out = hook(z.to(cuda)).cpu()
+        gold = torch.from_numpy(golden_vae[c["name"] + "/sub"])
+        err = (out[:, :, ::s, ::s] - gold).abs().max().item() / gold.abs().max().item()
+        assert err < 1e-3, f"{c['name']}: rel err {err}"
+        mom = golden_vae[c["name"] + "/moments"]
+        assert abs(out.double().sum().item() - mom[0]) < 1e-3 * max(1.0, abs(mom[0]), (mom[1]) ** 0.5)
+        assert abs((out.double() ** 2).sum().item() - mom[1]) < 2e-3 * mom[1]
+
+
+@pytest.mark.parametrize("fast", [True, False])
+def test_tiled_decode_full_width_decoder(plugin, cuda, fast):
+    """The real SD/SDXL decoder widths (ch=128: 512/512/256/128 channels, attention at C=512) on a small latent."""
+    dec_cpu = ld.make_decoder(3)
+    torch.manual_seed(5)
+    z = torch.randn(1, 4, 34, 42)
+    ref = vo.tiled_forward(dec_cpu, z, 12, fast)
+    dec = ld.make_decoder(3).to(cuda)
+    dec.original_forward = dec.forward
+    hook = plugin.tilevae.VAEHook(dec, 12, is_decoder=True, fast_decoder=fast, fast_encoder=False, color_fix=False)
+    out = hook(z.to(cuda)).cpu()
+    err = _rel(out, ref)
+    assert err < 1e-3, f"full-width tiled decode (fast={fast}): rel err {err}"
+
+
+def test_untiled_small_input_takes_original_forward(plugin, cuda):
+    dec = ld.make_decoder(0, small=True).to(cuda)
+    dec.original_forward = dec.forward
+    hook = plugin.tilevae.VAEHook(dec, 64, is_decoder=True, fast_decoder=True, fast_encoder=False, color_fix=False)
+    z = torch.randn(1, 4, 48, 48, device=cuda)
+    assert torch.equal(hook(z), dec.original_forward(z))   # max(H,W) <= 2*11 + 64  (tilevae.py:381-384)

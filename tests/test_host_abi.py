@@ -1,0 +1,91 @@
+"""C-ABI checks that need no GPU: the library loads, exports exactly what include/mdtile.h declares, the host-integer
+entry points (grid plan, VAE tile split) reproduce the upstream goldens, and the product path refuses to run on CPU."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "mdtile.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mdtile_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(built_lib):
+    names = _header_functions()
+    assert len(names) >= 30
+    lib = ctypes.CDLL(built_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"libmdtile.so does not export {n}"
+    # and the Python binding covers the whole header, nothing more, nothing less
+    assert sorted(built_lib.exported_symbols()) == names
+
+
+def test_only_c_symbols_are_public(built_lib):
+    out = subprocess.run(["nm", "-D", "--defined-only", built_lib.LIB_PATH], capture_output=True, text=True).stdout
+    public = [l.split()[-1] for l in out.splitlines() if " T " in l]
+    assert all(s.startswith("mdtile_") or s.startswith("_Z") or s.startswith("__") or s in ("_init", "_fini") for s in public)
+    assert "mdtile_blend" in public and "mdtile_vae_attn" in public
+
+
+def test_version_and_error_text(built_lib):
+    L = built_lib.lib()
+    assert L.mdtile_version() == 100
+    assert L.mdtile_plan_create(0, 0, 0, 0, 0, 0, 1) is None
+    assert b"bad arguments" in L.mdtile_last_error()
+
+
+def test_plan_matches_upstream_grids(built_lib, cases):
+    for g in cases["grid"]:
+        w, h, tw, th, ov, bs = g["args"]
+        p = built_lib.Plan(w, h, tw, th, ov, bs)
+        assert [list(b) for b in p.bboxes] == g["boxes"], g["args"]
+        assert p.num_batches == g["num_batches"] and p.tile_bs == g["tile_bs"]
+        assert sum(len(b) for b in p.batches) == len(g["boxes"])
+
+
+def test_plan_overlap_clamp_uses_requested_tile(built_lib):
+    # upstream clamps overlap with the REQUESTED tile size (abstractdiffusion.py:176-178): tile 96 on a 40-px canvas
+    p = built_lib.Plan(40, 40, 96, 96, 48, 4)
+    assert (p.tile_w, p.tile_h, p.overlap, p.num_tiles) == (40, 40, 48, 1)
+    with pytest.raises(built_lib.MdtileError):
+        built_lib.Plan(48, 100, 96, 96, 48, 4)   # clamped tile == overlap -> ZeroDivisionError upstream
+
+
+def test_vae_split_tiles_matches_upstream(built_lib, cases):
+    for t in cases["tiles"]:
+        h, w, ts, is_dec = t["args"]
+        ins, outs = built_lib.vae_split_tiles(h, w, ts, is_dec)
+        assert ins == t["ins"] and outs == t["outs"], t["args"]
+
+
+def test_no_cpu_fallback(built_lib):
+    x = torch.zeros(1, 4, 16, 16)
+    with pytest.raises(built_lib.MdtileError, match="no CPU fallback"):
+        built_lib.gather_rect(x, 0, 0, 4, 4)
+    with pytest.raises(built_lib.MdtileError, match="no CPU fallback"):
+        built_lib.gn_stats(torch.zeros(1, 32, 4, 4))
+    with pytest.raises(built_lib.MdtileError):
+        built_lib.gaussian_weights(8, 8, "cpu")
+
+
+def test_missing_library_fails_loudly(built_lib, monkeypatch):
+    monkeypatch.setattr(built_lib, "_lib", None)
+    monkeypatch.setattr(built_lib, "LIB_PATH", "/nonexistent/libmdtile.so")
+    with pytest.raises(built_lib.MdtileError, match="no CPU/eager fallback"):
+        built_lib.lib()
+
+
+def test_product_never_imports_oracle():
+    plug = os.path.join(ROOT, "multidiffusion-upscaler-for-automatic1111_amd")
+    for dp, _, files in os.walk(plug):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "oracle" not in txt.replace("test oracle", ""), f"{f} mentions the oracle"

@@ -1,0 +1,74 @@
+"""The A1111 plugin surface the host binds to (SURVEY.md section 8b outer boundary) -- no GPU needed."""
+import inspect
+
+import pytest
+
+from oracle import stub_host as sh
+
+
+def test_script_titles_and_visibility(plugin):
+    td, tv = plugin.tilediffusion.Script(), plugin.tilevae.Script()
+    assert td.title() == "Tiled Diffusion" and tv.title() == "Tiled VAE"
+    import modules.scripts as scripts
+    assert td.show(False) is scripts.AlwaysVisible and tv.show(True) is scripts.AlwaysVisible
+
+
+def test_process_argument_order_matches_upstream(plugin):
+    # upstream scripts/tilediffusion.py:257-266 and scripts/tilevae.py:704-708 (gradio passes values positionally)
+    td = list(inspect.signature(plugin.tilediffusion.Script.process).parameters)
+    assert td == ["self", "p", "enabled", "method", "overwrite_size", "keep_input_size", "image_width", "image_height",
+                  "tile_width", "tile_height", "overlap", "tile_batch_size", "upscaler_name", "scale_factor",
+                  "noise_inverse", "noise_inverse_steps", "noise_inverse_retouch", "noise_inverse_renoise_strength",
+                  "noise_inverse_renoise_kernel", "control_tensor_cpu", "enable_bbox_control", "draw_background",
+                  "causal_layers", "bbox_control_states"]
+    tv = list(inspect.signature(plugin.tilevae.Script.process).parameters)
+    assert tv == ["self", "p", "enabled", "encoder_tile_size", "decoder_tile_size", "vae_to_gpu", "fast_decoder",
+                  "fast_encoder", "color_fix"]
+
+
+def test_delegate_method_names(plugin):
+    md, mod = plugin.multidiffusion.MultiDiffusion, plugin.mixtureofdiffusers.MixtureOfDiffusers
+    for name in ("hook", "unhook", "kdiff_forward", "ddim_forward", "sample_one_step", "repeat_tensor", "repeat_cond_dict",
+                 "get_noise", "init_grid_bbox", "init_custom_bbox", "init_done", "reset_buffer", "get_tile_weights"):
+        assert callable(getattr(md, name)), name
+    for name in ("hook", "unhook", "apply_model_hijack", "custom_apply_model", "get_noise", "init_done", "get_tile_weights"):
+        assert callable(getattr(mod, name)), name
+    vh = plugin.tilevae.VAEHook
+    for name in ("__call__", "split_tiles", "get_best_tile_size", "estimate_group_norm", "vae_tile_forward"):
+        assert callable(getattr(vh, name)), name
+    assert list(inspect.signature(vh.__init__).parameters) == ["self", "net", "tile_size", "is_decoder", "fast_decoder",
+                                                                "fast_encoder", "color_fix", "to_gpu"]
+
+
+def test_bbox_settings_and_splitable(plugin):
+    U = plugin.utils
+    assert U.NUM_BBOX_PARAMS == 10 and U.BBoxSettings._fields[0] == "enable" and U.BBoxSettings._fields[-1] == "seed"
+    states = [True, 0.123456, 0.2, 0.30004, 0.5, "a", "b", "Background", 0.21234, 7.0,
+              False, 0.1, 0.1, 0.1, 0.1, "", "", "Background", 0.2, -1,
+              True, 1.5, 0.1, 0.1, 0.1, "", "", "Foreground", 0.2, -1]
+    s = U.build_bbox_settings(states)
+    assert list(s) == [0] and s[0].x == 0.1235 and s[0].w == 0.3 and s[0].feather_ratio == 0.2123 and s[0].seed == 7
+    assert U.splitable(2048, 2048, 96, 96, 48) and not U.splitable(512, 512, 96, 96, 48)
+    assert U.Method.MULTI_DIFF == "MultiDiffusion" and U.Method("Mixture of Diffusers") == U.Method.MIX_DIFF
+    b = U.BBox(3, 5, 10, 20)
+    assert b.box == [3, 5, 13, 25] and b.slicer[2] == slice(5, 25) and b[2] == 13
+
+
+def test_tilediffusion_process_arms_and_restores_hijack(plugin):
+    import modules.sd_samplers as sd_samplers
+    orig = sd_samplers.create_sampler
+    s = plugin.tilediffusion.Script()
+    p = sh.make_processing(2048, 2048)
+    p.extra_generation_params = {}
+    defaults = list(plugin.utils.DEFAULT_BBOX_SETTINGS) * 8
+    s.process(p, True, "MultiDiffusion", False, True, 1024, 1024, 96, 96, 48, 4, "None", 2.0, False, 10, 1, 1, 64, False,
+              False, False, False, *defaults)
+    assert sd_samplers.create_sampler is not orig and "Tiled Diffusion" in p.extra_generation_params
+    s.postprocess(p, None, True)
+    assert sd_samplers.create_sampler is orig
+    # a canvas that fits one tile arms nothing
+    p2 = sh.make_processing(512, 512)
+    p2.extra_generation_params = {}
+    s.process(p2, True, "MultiDiffusion", False, True, 1024, 1024, 96, 96, 48, 4, "None", 2.0, False, 10, 1, 1, 64, False,
+              False, False, False, *defaults)
+    assert sd_samplers.create_sampler is orig
