@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--slow-vae", action="store_true", help="slow-mode GroupNorm (pooled per norm) instead of fast mode")
     ap.add_argument("--no-vae", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-vae-latent", type=int, default=96)
+    ap.add_argument("--cpu-vae-latent", type=int, default=88, help="width of the 64-row latent of the CPU VAE sample")
     return ap.parse_args()
 
 
@@ -269,7 +269,6 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import blend_oracle as bo, vae_oracle as vo
         cores = os.cpu_count() or 1
-        torch.set_num_threads(cores)
         o = bo.BlendOracle(args.method, L, L, args.tile, args.tile, args.overlap, args.tile_bs)
         xc = x_in.cpu()
         pre = [t.cpu() for t in torch.split(tile_out, [len(b) * N for b in plan.batches])]
@@ -278,26 +277,46 @@ def main():
         def replay(_x):
             return next(it)
 
-        ts = []
-        for _ in range(4):
-            it = iter(pre)
-            t0 = time.perf_counter()
-            o.evaluate(xc, replay)
-            ts.append(time.perf_counter() - t0)
-        cpu_blend = sorted(ts)[len(ts) // 2]
-        sample = f"blend: median of 4 full {L}x{L} evaluations"
+        # eager-torch sliced adds do not scale to hundreds of threads (the full pool is ~1000x slower than 8 threads on a
+        # 256-core host): time a few pool sizes, report the fastest and the thread count it used
+        best_blend = None
+        for nt in sorted({min(cores, 8), min(cores, 32), cores}):
+            torch.set_num_threads(nt)
+            ts = []
+            for _ in range(3):
+                it = iter(pre)
+                t0 = time.perf_counter()
+                o.evaluate(xc, replay)
+                ts.append(time.perf_counter() - t0)
+                if ts[-1] > 5.0:
+                    break
+            med = sorted(ts)[len(ts) // 2]
+            if best_blend is None or med < best_blend[0]:
+                best_blend = (med, nt)
+        cpu_blend, blend_threads = best_blend
+        sample = f"blend: median of <=3 full {L}x{L} evaluations on {blend_threads} threads (best of 8/32/{cores})"
         cpu_val = L * L / (args.evals * cpu_blend)
         if hook is not None:
-            cl = args.cpu_vae_latent
+            # bounded sample: ONE tiled decode of a 64x88 latent at decoder tile 64 (the reference's own non-CUDA default,
+            # tilevae.py:98) = 2 padded tiles; timed at two thread counts, the faster one is reported (a 256-thread pool
+            # is slower than 32 threads on these small per-tile convs)
+            ch, cw = 64, args.cpu_vae_latent
             dcpu = ld.make_decoder(0)
-            zc = torch.randn(1, 4, cl, cl, generator=torch.Generator().manual_seed(2))
-            t0 = time.perf_counter()
-            vo.tiled_forward(dcpu, zc, 64, fast=not args.slow_vae)
-            cpu_vae = time.perf_counter() - t0
-            per_px = args.evals * cpu_blend / (L * L) + cpu_vae / (cl * cl)
+            zc = torch.randn(1, 4, ch, cw, generator=torch.Generator().manual_seed(2))
+            best = None
+            for nt in sorted({min(cores, 32), cores}):
+                torch.set_num_threads(nt)
+                t0 = time.perf_counter()
+                vo.tiled_forward(dcpu, zc, 64, fast=not args.slow_vae)
+                dt = time.perf_counter() - t0
+                if best is None or dt < best[0]:
+                    best = (dt, nt)
+            cpu_vae, vae_threads = best
+            per_px = args.evals * cpu_blend / (L * L) + cpu_vae / (ch * cw)
             cpu_val = 1.0 / per_px
-            sample += f"; VAE: one tiled decode of a {cl}x{cl} latent at decoder tile 64 (the reference's CPU default), {cpu_vae:.1f} s; rates combined per latent px"
-        cpu_baseline = {"value": round(cpu_val, 1), "unit": "latent-px/s", "cores": cores, "kind": "port", "sample": sample,
+            sample += (f"; VAE: one tiled decode of a {cw}x{ch} latent at decoder tile 64 (the reference's CPU default), "
+                       f"{cpu_vae:.1f} s on {vae_threads} threads; rates combined per latent px")
+        cpu_baseline = {"value": round(cpu_val, 1), "unit": "latent-px/s", "cores": max(blend_threads, vae_threads if hook is not None else 0), "host_cores": cores, "kind": "port", "sample": sample,
                         "blend_eval_ms": round(cpu_blend * 1e3, 2)}
 
     if rank == 0:

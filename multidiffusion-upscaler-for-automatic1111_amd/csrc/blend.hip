@@ -10,9 +10,11 @@
 //     (this file is compiled with -ffp-contract=off so `a*b + c` stays two roundings, as in eager torch).
 // HBM-bound: algorithmic bytes = s*(T*N*C*th*tw + N*C*H*W) + 4*H*W.
 //
-// Access pattern: a thread owns 4 consecutive canvas columns of one (n,c) plane -> 16 B per lane, 1 KiB contiguous
-// per wave on the store side; tile-side reads are 4-element vectors at an element-aligned (not 16 B-aligned) address
-// because tile origins are arbitrary (gfx950 unaligned-access mode: one global_load_dwordx4).
+// Access pattern: a thread owns 4 consecutive canvas columns of one row for 8 (n,c) planes -> 16 B per lane and plane,
+// 1 KiB contiguous per wave and plane on the store side; tile-side reads are 4-element vectors at an element-aligned
+// (not 16 B-aligned) address because tile origins are arbitrary (gfx950 unaligned-access mode: one global_load_dwordx4).
+// No LDS staging and no cross-lane reduction is needed in this formulation: the sum over covering tiles is a short
+// in-register loop (1 tile for ~75 % of the pixels at overlap 8, at most 4 in the corners of the overlap lattice).
 #include "common.h"
 
 using namespace mdt;
@@ -30,17 +32,6 @@ struct BlendParams {
     const void* batch[MDTILE_MAX_BATCHES];
 };
 static_assert(sizeof(BlendParams) <= 4096, "kernel argument block must stay under 4 KiB");
-
-template <typename T>
-__device__ __forceinline__ const T* tile_ptr(const BlendParams& P, int t, int plane_n, int plane_c) {
-    // tile-major batch layout: tile i of a batch occupies rows [i*N, (i+1)*N) (multidiffusion.py:155,167)
-    size_t tile_elems = (size_t)P.th * P.tw;
-    if (P.flags & MDTILE_BLEND_PACKED) {
-        return reinterpret_cast<const T*>(P.batch[0]) + (((size_t)t * P.N + plane_n) * P.C + plane_c) * tile_elems;
-    }
-    int b = t / P.tile_bs, i = t - b * P.tile_bs;
-    return reinterpret_cast<const T*>(P.batch[b]) + (((size_t)i * P.N + plane_n) * P.C + plane_c) * tile_elems;
-}
 
 // Shared epilogue: MD normalisation (multidiffusion.py:208) and the foreground feather composite
 // (multidiffusion.py:211-216 == mixtureofdiffusers.py:170-175), for one pixel.
@@ -72,7 +63,20 @@ __device__ __forceinline__ float epilogue_px(const BlendParams& P, float acc, in
     return v;
 }
 
-template <typename T, int METHOD>
+// One thread owns 4 consecutive canvas columns of one row for PP (n,c) planes at once: the covering-tile lookup
+// (rowrange / colrange / xs / ys, four small dependent loads) is done once and amortised over PP planes, and the PP
+// 16-byte tile loads of one covering tile are independent -> PP loads in flight per lane before the first use.
+// Plane p = n*C + c sits at `tile base + p * th*tw` in the tile-major batch layout, so the planes of one tile are a
+// fixed stride apart.
+template <typename T>
+__device__ __forceinline__ const T* tile_base(const BlendParams& P, int t) {
+    const size_t tile_elems = (size_t)P.th * P.tw;
+    if (P.flags & MDTILE_BLEND_PACKED) return reinterpret_cast<const T*>(P.batch[0]) + (size_t)t * P.N * P.C * tile_elems;
+    const int b = t / P.tile_bs, i = t - b * P.tile_bs;
+    return reinterpret_cast<const T*>(P.batch[b]) + (size_t)i * P.N * P.C * tile_elems;
+}
+
+template <typename T, int METHOD, int PP>
 __global__ __launch_bounds__(256) void k_blend(const BlendParams P) {
     const int W4 = (P.W + 3) >> 2;
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -80,14 +84,21 @@ __global__ __launch_bounds__(256) void k_blend(const BlendParams P) {
     const int yq = idx / W4;
     const int y = P.row_lo + yq;
     const int x0 = (idx - yq * W4) << 2;
-    const int plane = blockIdx.y, n = plane / P.C, c = plane - n * P.C;
+    const int planes = P.N * P.C;
+    const int p0 = blockIdx.y * PP;
+    const int np = planes - p0 < PP ? planes - p0 : PP;   // wave-uniform
     const int nvalid = P.W - x0 < 4 ? P.W - x0 : 4;
+    const size_t tile_elems = (size_t)P.th * P.tw;
 
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    const int rr = P.rowrange[y];
-    const int r0 = rr & 0xffff, nr = rr >> 16;
+    float acc[PP][4];
+#pragma unroll
+    for (int pp = 0; pp < PP; ++pp)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[pp][j] = 0.f;
 
     if (P.num_batches > 0) {
+        const int rr = P.rowrange[y];
+        const int r0 = rr & 0xffff, nr = rr >> 16;
         const int cr0 = P.colrange[x0];
         const bool uniform = nvalid == 4 && cr0 == P.colrange[x0 + 3];  // ranges are monotone: ends equal => all equal
         if (uniform) {
@@ -99,25 +110,35 @@ __global__ __launch_bounds__(256) void k_blend(const BlendParams P) {
                 for (int cc = c0; cc < c0 + nc; ++cc) {
                     const int t = r * P.cols + cc;
                     if ((P.flags & MDTILE_BLEND_TILE_RANGE) && (t < P.tile_lo || t >= P.tile_hi)) continue;
-                    const int tx = x0 - P.xs[cc];
-                    float v[4];
-                    load4<T>(tile_ptr<T>(P, t, n, c) + (size_t)ty * P.tw + tx, v);
-                    if (METHOD == MDTILE_METHOD_MOD) {
-                        float g[4];
-                        load4<float>(P.tile_w + (size_t)ty * P.tw + tx, g);
+                    const size_t toff = (size_t)ty * P.tw + (x0 - P.xs[cc]);
+                    const T* src = tile_base<T>(P, t) + (size_t)p0 * tile_elems + toff;
+                    float v[PP][4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            float wgt = g[j] * resc[j];  // w = tile_weights * rescale_factor[slicer]   (mixtureofdiffusers.py:125)
-                            acc[j] += v[j] * wgt;        // x_buffer[slicer] += out * w                (mixtureofdiffusers.py:126)
-                        }
+                    for (int pp = 0; pp < PP; ++pp)
+                        if (pp < np) load4<T>(src + (size_t)pp * tile_elems, v[pp]);
+                    if (METHOD == MDTILE_METHOD_MOD) {
+                        float g[4], wgt[4];
+                        load4<float>(P.tile_w + toff, g);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) wgt[j] = g[j] * resc[j];  // w = tile_weights * rescale_factor[slicer]  (mixtureofdiffusers.py:125)
+#pragma unroll
+                        for (int pp = 0; pp < PP; ++pp)
+                            if (pp < np)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) acc[pp][j] += v[pp][j] * wgt[j];  // x_buffer[slicer] += out * w  (:126)
                     } else {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[j] += v[j];  // multidiffusion.py:167
+                        for (int pp = 0; pp < PP; ++pp)
+                            if (pp < np)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) acc[pp][j] += v[pp][j];           // multidiffusion.py:167
                     }
                 }
             }
         } else {
-            for (int j = 0; j < nvalid; ++j) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j >= nvalid) continue;
                 const int x = x0 + j;
                 const int cr = P.colrange[x];
                 const int c0 = cr & 0xffff, nc = cr >> 16;
@@ -126,13 +147,16 @@ __global__ __launch_bounds__(256) void k_blend(const BlendParams P) {
                     for (int cc = c0; cc < c0 + nc; ++cc) {
                         const int t = r * P.cols + cc;
                         if ((P.flags & MDTILE_BLEND_TILE_RANGE) && (t < P.tile_lo || t >= P.tile_hi)) continue;
-                        const int tx = x - P.xs[cc];
-                        float v = to_f32<T>(tile_ptr<T>(P, t, n, c)[(size_t)ty * P.tw + tx]);
-                        if (METHOD == MDTILE_METHOD_MOD) {
-                            float wgt = P.tile_w[(size_t)ty * P.tw + tx] * P.rescale[(size_t)y * P.W + x];
-                            acc[j] += v * wgt;
-                        } else {
-                            acc[j] += v;
+                        const size_t toff = (size_t)ty * P.tw + (x - P.xs[cc]);
+                        const T* src = tile_base<T>(P, t) + (size_t)p0 * tile_elems + toff;
+                        float wgt = 1.0f;
+                        if (METHOD == MDTILE_METHOD_MOD) wgt = P.tile_w[toff] * P.rescale[(size_t)y * P.W + x];
+#pragma unroll
+                        for (int pp = 0; pp < PP; ++pp) {
+                            if (pp >= np) continue;
+                            const float v = to_f32<T>(src[(size_t)pp * tile_elems]);
+                            if (METHOD == MDTILE_METHOD_MOD) acc[pp][j] += v * wgt;
+                            else acc[pp][j] += v;
                         }
                     }
                 }
@@ -146,29 +170,90 @@ __global__ __launch_bounds__(256) void k_blend(const BlendParams P) {
         if (R.mode != MDTILE_REGION_BG) continue;
         const int ry = y - R.y;
         if (ry < 0 || ry >= R.h) continue;
-        for (int j = 0; j < nvalid; ++j) {
+        const size_t rplane = (size_t)R.h * R.w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
             const int rx = x0 + j - R.x;
-            if (rx < 0 || rx >= R.w) continue;
+            if (j >= nvalid || rx < 0 || rx >= R.w) continue;
             const size_t off = (size_t)ry * R.w + rx;
-            float v = to_f32<T>(reinterpret_cast<const T*>(R.out)[((size_t)n * P.C + c) * R.h * R.w + off]);
-            if (METHOD == MDTILE_METHOD_MOD) acc[j] += v * R.weight[off];
-            else acc[j] += v;
+            const T* src = reinterpret_cast<const T*>(R.out) + (size_t)p0 * rplane + off;
+            const float wgt = METHOD == MDTILE_METHOD_MOD ? R.weight[off] : 1.0f;
+#pragma unroll
+            for (int pp = 0; pp < PP; ++pp) {
+                if (pp >= np) continue;
+                const float v = to_f32<T>(src[(size_t)pp * rplane]);
+                if (METHOD == MDTILE_METHOD_MOD) acc[pp][j] += v * wgt;
+                else acc[pp][j] += v;
+            }
         }
     }
 
-    const size_t o = (((size_t)n * P.C + c) * P.H + y) * P.W + x0;
+    const size_t plane_px = (size_t)P.H * P.W;
+    const size_t o = ((size_t)p0 * P.H + y) * P.W + x0;
     if (P.flags & MDTILE_BLEND_PARTIAL) {  // raw fp32 sums; the epilogue runs after the cross-rank sum
-        float* dst = reinterpret_cast<float*>(P.out) + o;
-        if (nvalid == 4) store4<float>(dst, acc);
-        else for (int j = 0; j < nvalid; ++j) dst[j] = acc[j];
+#pragma unroll
+        for (int pp = 0; pp < PP; ++pp) {
+            if (pp >= np) continue;
+            float* dst = reinterpret_cast<float*>(P.out) + o + (size_t)pp * plane_px;
+            if (nvalid == 4) store4<float>(dst, acc[pp]);
+            else for (int j = 0; j < nvalid; ++j) dst[j] = acc[pp][j];
+        }
         return;
     }
-    float res[4];
+
+    // MD normalisation: x = where(weights > 1, buf / weights, buf)  (multidiffusion.py:208); the weight is per pixel, shared by planes
+    if (METHOD == MDTILE_METHOD_MD) {
+        float w[4] = {1.f, 1.f, 1.f, 1.f};
+        if (nvalid == 4) load4<float>(P.weights + (size_t)y * P.W + x0, w);
+        else for (int j = 0; j < nvalid; ++j) w[j] = P.weights[(size_t)y * P.W + x0 + j];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) res[j] = j < nvalid ? epilogue_px<T, METHOD>(P, acc[j], n, c, y, x0 + j) : 0.f;
-    T* dst = reinterpret_cast<T*>(P.out) + o;
-    if (nvalid == 4) store4<T>(dst, res);
-    else for (int j = 0; j < nvalid; ++j) dst[j] = from_f32<T>(res[j]);
+        for (int pp = 0; pp < PP; ++pp)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[pp][j] = w[j] > 1.0f ? acc[pp][j] / w[j] : acc[pp][j];
+    }
+
+    // foreground feather composite (multidiffusion.py:191-198, 211-216 == mixtureofdiffusers.py:154-161, 170-175)
+    bool any_fg = false;
+    for (int k = 0; k < P.num_regions; ++k) any_fg |= P.regions[k].mode == MDTILE_REGION_FG;
+    if (any_fg) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j >= nvalid) continue;
+            float fbuf[PP], fmask = 0.0f, fcnt = 0.0f;
+#pragma unroll
+            for (int pp = 0; pp < PP; ++pp) fbuf[pp] = 0.0f;
+            for (int k = 0; k < P.num_regions; ++k) {
+                const mdtile_region& R = P.regions[k];
+                if (R.mode != MDTILE_REGION_FG) continue;
+                const int ry = y - R.y, rx = x0 + j - R.x;
+                if (ry < 0 || ry >= R.h || rx < 0 || rx >= R.w) continue;
+                const size_t rplane = (size_t)R.h * R.w, off = (size_t)ry * R.w + rx;
+                const T* src = reinterpret_cast<const T*>(R.out) + (size_t)p0 * rplane + off;
+#pragma unroll
+                for (int pp = 0; pp < PP; ++pp)
+                    if (pp < np) fbuf[pp] += to_f32<T>(src[(size_t)pp * rplane]);
+                fmask += R.weight[off];
+                fcnt += 1.0f;
+            }
+            if (fcnt > 0.0f) {
+                if (fcnt > 1.0f) fmask = fmask / fcnt;
+#pragma unroll
+                for (int pp = 0; pp < PP; ++pp) {
+                    float fb = fbuf[pp];
+                    if (fcnt > 1.0f) fb = fb / fcnt;
+                    acc[pp][j] = acc[pp][j] * (1.0f - fmask) + fb * fmask;
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int pp = 0; pp < PP; ++pp) {
+        if (pp >= np) continue;
+        T* dst = reinterpret_cast<T*>(P.out) + o + (size_t)pp * plane_px;
+        if (nvalid == 4) store4<T>(dst, acc[pp]);
+        else for (int j = 0; j < nvalid; ++j) dst[j] = from_f32<T>(acc[pp][j]);
+    }
 }
 
 template <typename T, int METHOD>
@@ -241,9 +326,10 @@ int launch_blend(const BlendParams& P, int method, bool finalize, hipStream_t s)
         if (method == MDTILE_METHOD_MD) hipLaunchKernelGGL((k_blend_finalize<T, MDTILE_METHOD_MD>), grid, block, 0, s, P);
         else hipLaunchKernelGGL((k_blend_finalize<T, MDTILE_METHOD_MOD>), grid, block, 0, s, P);
     } else {
-        dim3 grid(cdiv((long long)P.nrows * ((P.W + 3) / 4), 256), P.N * P.C);
-        if (method == MDTILE_METHOD_MD) hipLaunchKernelGGL((k_blend<T, MDTILE_METHOD_MD>), grid, block, 0, s, P);
-        else hipLaunchKernelGGL((k_blend<T, MDTILE_METHOD_MOD>), grid, block, 0, s, P);
+        constexpr int PP = 8;  // planes per thread: N*C = 8 for batch-1 CFG (cond + uncond) x 4 latent channels
+        dim3 grid(cdiv((long long)P.nrows * ((P.W + 3) / 4), 256), cdiv(P.N * P.C, PP));
+        if (method == MDTILE_METHOD_MD) hipLaunchKernelGGL((k_blend<T, MDTILE_METHOD_MD, PP>), grid, block, 0, s, P);
+        else hipLaunchKernelGGL((k_blend<T, MDTILE_METHOD_MOD, PP>), grid, block, 0, s, P);
     }
     MDT_LAUNCH_CHECK();
     return MDTILE_OK;

@@ -64,13 +64,15 @@ def _test_for_nans(x, where):
         raise NansException(f"A tensor with NaNs was produced in {where}.")
 
 
-def install(device: str | torch.device = "cpu") -> types.ModuleType:
-    """Register the fake host modules in sys.modules (idempotent). Returns `modules.shared`."""
+def install(device: str | torch.device | None = None) -> types.ModuleType:
+    """Register the fake host modules in sys.modules (idempotent). Returns `modules.shared`.
+    `device=None` keeps the current `devices.device` of an already-installed stub (cpu on first install)."""
     global _INSTALLED
-    dev = torch.device(device)
     if _INSTALLED:
-        set_device(dev)
+        if device is not None:
+            set_device(device)
         return sys.modules["modules.shared"]
+    dev = torch.device(device if device is not None else "cpu")
 
     sys.dont_write_bytecode = True  # /root/reference is a read-only mount
 
@@ -84,15 +86,17 @@ def install(device: str | torch.device = "cpu") -> types.ModuleType:
         def ui(self, is_img2img):
             return []
 
-    class KDiffusionSampler:  # isinstance() is used on these (abstractdiffusion.py:77-83)
-        pass
-
-    class CompVisSampler:
-        pass
-
     class _Denoiser:
         def forward(self, *a, **k):
             raise NotImplementedError
+
+    class KDiffusionSampler:  # isinstance() is used on these (abstractdiffusion.py:77-83)
+        def __init__(self):
+            # what the delegates read from the CFG denoiser wrapper (abstractdiffusion.py:17-20, 240)
+            self.model_wrap_cfg = SimpleNamespace(image_cfg_scale=None, step=0, inner_model=_Denoiser())
+
+    class CompVisSampler:
+        pass
 
     class LatentDiffusion:
         def apply_model(self, *a, **k):
