@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--slow-vae", action="store_true", help="slow-mode GroupNorm (pooled per norm) instead of fast mode")
     ap.add_argument("--no-vae", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile-pass", action="store_true", help="skip the per-stage split and the HIP-event roofline pass (PMC runs)")
     ap.add_argument("--cpu-vae-latent", type=int, default=88, help="width of the 64-row latent of the CPU VAE sample")
     return ap.parse_args()
 
@@ -193,7 +194,7 @@ def main():
         sync_all()
         t_blend_eval = (time.perf_counter() - tb) / args.evals
         t_vae = None
-        if hook is not None:
+        if hook is not None and not args.no_profile_pass:
             tv = time.perf_counter()
             hook(z)
             sync_all()
@@ -209,7 +210,7 @@ def main():
 
     # ------------------------------------------------------------------ per-kernel roofline (instrumented extra pass)
     roofline = roofline_blend = None
-    if rank == 0:
+    if rank == 0 and not args.no_profile_pass:
         prof = Profile()
         s_bytes = 4
         T_local = plan.num_tiles if world == 1 else n_local

@@ -198,4 +198,15 @@ def test_untiled_small_input_takes_original_forward(plugin, cuda):
     dec.original_forward = dec.forward
     hook = plugin.tilevae.VAEHook(dec, 64, is_decoder=True, fast_decoder=True, fast_encoder=False, color_fix=False)
     z = torch.randn(1, 4, 48, 48, device=cuda)
-    assert torch.equal(hook(z), dec.original_forward(z))   # max(H,W) <= 2*11 + 64  (tilevae.py:381-384)
+    calls = []
+    inner = dec.original_forward
+
+    def spy(x):
+        calls.append(tuple(x.shape))
+        return inner(x)
+
+    dec.original_forward = spy
+    out = hook(z)                                           # max(H,W) <= 2*11 + 64  (tilevae.py:381-384)
+    assert calls == [(1, 4, 48, 48)], "tiny inputs must be handed to the untouched original forward"
+    # the host's own (MIOpen) convs are not run-to-run bit-stable on this stack: compare with a tolerance
+    assert torch.allclose(out, inner(z), rtol=1e-4, atol=1e-5)
