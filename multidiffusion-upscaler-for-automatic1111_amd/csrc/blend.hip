@@ -15,16 +15,21 @@
 // (not 16 B-aligned) address because tile origins are arbitrary (gfx950 unaligned-access mode: one global_load_dwordx4).
 // No LDS staging and no cross-lane reduction is needed in this formulation: the sum over covering tiles is a short
 // in-register loop (1 tile for ~75 % of the pixels at overlap 8, at most 4 in the corners of the overlap lattice).
+#include <type_traits>
+
 #include "common.h"
 
 using namespace mdt;
+
+#define MDT_DEBUG_SKIP_NORM 0x100  // probing only: MultiDiffusion without the weights>1 division
 
 namespace {
 
 struct BlendParams {
     int W, H, tw, th, cols, tile_bs, N, C;
-    int flags, tile_lo, tile_hi, row_lo, nrows, num_regions, num_batches, _pad;
+    int flags, tile_lo, tile_hi, row_lo, nrows, num_regions, num_batches, num_fg;
     const int *xs, *ys, *colrange, *rowrange;
+    const int4 *colquad, *rowinfo;
     const float *weights, *tile_w, *rescale;
     void* out;
     const float* partial;  // finalize only
@@ -63,30 +68,41 @@ __device__ __forceinline__ float epilogue_px(const BlendParams& P, float acc, in
     return v;
 }
 
-// One thread owns 4 consecutive canvas columns of one row for PP (n,c) planes at once: the covering-tile lookup
-// (rowrange / colrange / xs / ys, four small dependent loads) is done once and amortised over PP planes, and the PP
-// 16-byte tile loads of one covering tile are independent -> PP loads in flight per lane before the first use.
-// Plane p = n*C + c sits at `tile base + p * th*tw` in the tile-major batch layout, so the planes of one tile are a
-// fixed stride apart.
-template <typename T>
+// One thread owns 4 consecutive canvas columns (a "quad") of one row for PP (n,c) planes.
+//   * ONE 16-byte record per axis (plan tables colquad / rowinfo) tells the thread which tile columns / rows cover it and
+//     their origins: a single dependent hop before the streaming loads (the old colrange -> xs -> tile chain had three).
+//   * the covering tiles are walked in upstream's list order (row-major tile index) in chunks of G candidates; all G*PP
+//     16-byte loads of a chunk are issued before the first add, so a lane has up to G*PP KiB-wide wave loads in flight.
+//   * plane p = n*C + c of tile t sits at `tile base + p * th*tw` (tile-major batch layout).
+// the <= 4 in-canvas floats of a quad, statically indexed (a runtime-indexed local array would be demoted to LDS/scratch)
+__device__ __forceinline__ void load_quad_f32(const float* p, int nvalid, float (&o)[4], float dflt) {
+    if (nvalid == 4) {
+        load4<float>(p, o);
+    } else {
+        o[0] = p[0];
+        o[1] = nvalid > 1 ? p[1] : dflt;
+        o[2] = nvalid > 2 ? p[2] : dflt;
+        o[3] = dflt;
+    }
+}
+
+template <typename T, bool PACKED>
 __device__ __forceinline__ const T* tile_base(const BlendParams& P, int t) {
     const size_t tile_elems = (size_t)P.th * P.tw;
-    if (P.flags & MDTILE_BLEND_PACKED) return reinterpret_cast<const T*>(P.batch[0]) + (size_t)t * P.N * P.C * tile_elems;
-    const int b = t / P.tile_bs, i = t - b * P.tile_bs;
+    if (PACKED) return reinterpret_cast<const T*>(P.batch[0]) + (size_t)t * P.N * P.C * tile_elems;
+    const int b = t / P.tile_bs, i = t - b * P.tile_bs;   // P.batch[b] with a per-lane b is a (cached) vector load
     return reinterpret_cast<const T*>(P.batch[b]) + (size_t)i * P.N * P.C * tile_elems;
 }
 
-template <typename T, int METHOD, int PP>
+template <typename T, int METHOD, int PP, int G, bool PACKED>
 __global__ __launch_bounds__(256) void k_blend(const BlendParams P) {
     const int W4 = (P.W + 3) >> 2;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= W4 * P.nrows) return;
-    const int yq = idx / W4;
+    const int yq = idx / W4, xq = idx - yq * W4;
     const int y = P.row_lo + yq;
-    const int x0 = (idx - yq * W4) << 2;
-    const int planes = P.N * P.C;
-    const int p0 = blockIdx.y * PP;
-    const int np = planes - p0 < PP ? planes - p0 : PP;   // wave-uniform
+    const int x0 = xq << 2;
+    const int p0 = blockIdx.y * PP;                        // the host guarantees N*C % PP == 0
     const int nvalid = P.W - x0 < 4 ? P.W - x0 : 4;
     const size_t tile_elems = (size_t)P.th * P.tw;
 
@@ -96,69 +112,143 @@ __global__ __launch_bounds__(256) void k_blend(const BlendParams P) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[pp][j] = 0.f;
 
+    // MD: the per-pixel weight sum for the epilogue, requested up front so its latency hides behind the tile loads
+    float wq[4] = {1.f, 1.f, 1.f, 1.f};
+    if (METHOD == MDTILE_METHOD_MD && !(P.flags & MDTILE_BLEND_PARTIAL)) load_quad_f32(P.weights + (size_t)y * P.W + x0, nvalid, wq, 1.0f);
+
     if (P.num_batches > 0) {
-        const int rr = P.rowrange[y];
-        const int r0 = rr & 0xffff, nr = rr >> 16;
-        const int cr0 = P.colrange[x0];
-        const bool uniform = nvalid == 4 && cr0 == P.colrange[x0 + 3];  // ranges are monotone: ends equal => all equal
-        if (uniform) {
-            const int c0 = cr0 & 0xffff, nc = cr0 >> 16;
-            float resc[4];
-            if (METHOD == MDTILE_METHOD_MOD) load4<float>(P.rescale + (size_t)y * P.W + x0, resc);
-            for (int r = r0; r < r0 + nr; ++r) {
-                const int ty = y - P.ys[r];
-                for (int cc = c0; cc < c0 + nc; ++cc) {
-                    const int t = r * P.cols + cc;
-                    if ((P.flags & MDTILE_BLEND_TILE_RANGE) && (t < P.tile_lo || t >= P.tile_hi)) continue;
-                    const size_t toff = (size_t)ty * P.tw + (x0 - P.xs[cc]);
-                    const T* src = tile_base<T>(P, t) + (size_t)p0 * tile_elems + toff;
-                    float v[PP][4];
+        const int4 cq = P.colquad[xq];
+        const int4 rq = P.rowinfo[y];
+        const int c0 = cq.x & 0xffff, nc = cq.x >> 16, r0 = rq.x & 0xffff, nr = rq.x >> 16;
+        // "clean" quad: all 4 px in the canvas and every candidate column contains the whole quad -> 16-byte loads.
+        // True for every quad when the tile origins are multiples of 4.  Other quads (a tile edge inside the quad, the
+        // ragged last quad of a row) take the same chunked walk with per-element loads at clamped addresses and a
+        // per-pixel coverage mask.  Only > 3 covering tiles per axis (overlap > 2/3 of the tile) falls to the generic walk.
+        // (Measured: folding both kinds of load into one walk is slower on clean grids -- more code per candidate.)
+        const bool small = nc <= 3 && nr <= 3;
+        bool clean = nvalid == 4 && small;
+        {
+            const int t0 = x0 - cq.y, t1 = x0 - cq.z, t2 = x0 - cq.w;
+            clean = clean && t0 >= 0 && t0 + 3 < P.tw;
+            if (nc > 1) clean = clean && t1 >= 0 && t1 + 3 < P.tw;
+            if (nc > 2) clean = clean && t2 >= 0 && t2 + 3 < P.tw;
+        }
+        auto chunked_walk = [&](auto vec_tag) {
+            constexpr bool VEC = decltype(vec_tag)::value;
+            const int total = nr * nc;
+            float resc[4] = {0.f, 0.f, 0.f, 0.f};
+            if (METHOD == MDTILE_METHOD_MOD) load_quad_f32(P.rescale + (size_t)y * P.W + x0, nvalid, resc, 0.f);
+            int rr = 0, cc = 0;  // running candidate, row-major == ascending tile index == upstream's list order
+            for (int s0 = 0; s0 < total; s0 += G) {
+                float v[G][PP][4], wg[G][4];
+                unsigned cov[G];      // bit j: pixel j of the quad is covered by candidate g (0xf for every live clean candidate)
+                const T* row[G];      // tile row start (+ tx for VEC)
+                size_t woff[G];       // same position inside the [th, tw] tile-weight map
+                int txs[G];
+                // phase A: addresses of the chunk's candidates (batch-pointer lookups, if any, all issued together)
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int xo = cc == 0 ? cq.y : (cc == 1 ? cq.z : cq.w);
+                    const int yo = rr == 0 ? rq.y : (rr == 1 ? rq.z : rq.w);
+                    const int t = (r0 + rr) * P.cols + c0 + cc;
+                    bool ok = s0 + g < total;
+                    if (P.flags & MDTILE_BLEND_TILE_RANGE) ok = ok && t >= P.tile_lo && t < P.tile_hi;
+                    const int tx = x0 - xo;
+                    unsigned m = 0xfu;
+                    if (!VEC) {
+                        m = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (j < nvalid && tx + j >= 0 && tx + j < P.tw) m |= 1u << j;
+                    }
+                    cov[g] = ok ? m : 0u;
+                    txs[g] = tx;
+                    woff[g] = (size_t)(y - yo) * P.tw + (VEC ? tx : 0);
+                    row[g] = tile_base<T, PACKED>(P, cov[g] ? t : 0) + (size_t)p0 * tile_elems + woff[g];
+                    ++cc;
+                    if (cc == nc) { cc = 0; ++rr; }
+                }
+                // phase B: every load of the chunk in flight before the first add
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
 #pragma unroll
                     for (int pp = 0; pp < PP; ++pp)
-                        if (pp < np) load4<T>(src + (size_t)pp * tile_elems, v[pp]);
-                    if (METHOD == MDTILE_METHOD_MOD) {
-                        float g[4], wgt[4];
-                        load4<float>(P.tile_w + toff, g);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) wgt[j] = g[j] * resc[j];  // w = tile_weights * rescale_factor[slicer]  (mixtureofdiffusers.py:125)
+                        for (int j = 0; j < 4; ++j) v[g][pp][j] = 0.f;
 #pragma unroll
-                        for (int pp = 0; pp < PP; ++pp)
-                            if (pp < np)
+                    for (int j = 0; j < 4; ++j) wg[g][j] = 0.f;
+                    if (cov[g]) {
+                        if (VEC) {                 // whole quad inside the tile: 16-byte loads
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) acc[pp][j] += v[pp][j] * wgt[j];  // x_buffer[slicer] += out * w  (:126)
-                    } else {
+                            for (int pp = 0; pp < PP; ++pp) load4<T>(row[g] + (size_t)pp * tile_elems, v[g][pp]);
+                            if (METHOD == MDTILE_METHOD_MOD) load4<float>(P.tile_w + woff[g], wg[g]);
+                        } else {                   // a tile edge inside the quad / ragged last quad: per-element loads
 #pragma unroll
-                        for (int pp = 0; pp < PP; ++pp)
-                            if (pp < np)
+                            for (int j = 0; j < 4; ++j) {
+                                int cx = txs[g] + j;          // clamped into the tile row: always a valid address
+                                cx = cx < 0 ? 0 : (cx >= P.tw ? P.tw - 1 : cx);
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) acc[pp][j] += v[pp][j];           // multidiffusion.py:167
+                                for (int pp = 0; pp < PP; ++pp) v[g][pp][j] = to_f32<T>(row[g][(size_t)pp * tile_elems + cx]);
+                                if (METHOD == MDTILE_METHOD_MOD) wg[g][j] = P.tile_w[woff[g] + cx];
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    if (!cov[g]) continue;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (!VEC && !((cov[g] >> j) & 1u)) continue;
+                        if (METHOD == MDTILE_METHOD_MOD) {
+                            const float w = wg[g][j] * resc[j];              // w = tile_weights * rescale_factor[slicer]  (mixtureofdiffusers.py:125)
+#pragma unroll
+                            for (int pp = 0; pp < PP; ++pp) acc[pp][j] += v[g][pp][j] * w;   // x_buffer[slicer] += out * w  (:126)
+                        } else {
+#pragma unroll
+                            for (int pp = 0; pp < PP; ++pp) acc[pp][j] += v[g][pp][j];       // multidiffusion.py:167
+                        }
                     }
                 }
             }
+        };
+        if (clean) {
+            chunked_walk(std::true_type{});
+        } else if (small) {
+            chunked_walk(std::false_type{});
         } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (j >= nvalid) continue;
+            // generic per-pixel walk through the colrange / rowrange / xs / ys tables
+#pragma unroll 1
+            for (int j = 0; j < nvalid; ++j) {
                 const int x = x0 + j;
-                const int cr = P.colrange[x];
-                const int c0 = cr & 0xffff, nc = cr >> 16;
-                for (int r = r0; r < r0 + nr; ++r) {
+                const int cr = P.colrange[x], rrg = P.rowrange[y];
+                const int pc0 = cr & 0xffff, pnc = cr >> 16, pr0 = rrg & 0xffff, pnr = rrg >> 16;
+                float a[PP];
+#pragma unroll
+                for (int pp = 0; pp < PP; ++pp) a[pp] = 0.f;
+                for (int r = pr0; r < pr0 + pnr; ++r) {
                     const int ty = y - P.ys[r];
-                    for (int cc = c0; cc < c0 + nc; ++cc) {
-                        const int t = r * P.cols + cc;
+                    for (int c = pc0; c < pc0 + pnc; ++c) {
+                        const int t = r * P.cols + c;
                         if ((P.flags & MDTILE_BLEND_TILE_RANGE) && (t < P.tile_lo || t >= P.tile_hi)) continue;
-                        const size_t toff = (size_t)ty * P.tw + (x - P.xs[cc]);
-                        const T* src = tile_base<T>(P, t) + (size_t)p0 * tile_elems + toff;
+                        const size_t toff = (size_t)ty * P.tw + (x - P.xs[c]);
+                        const T* src = tile_base<T, PACKED>(P, t) + (size_t)p0 * tile_elems + toff;
                         float wgt = 1.0f;
                         if (METHOD == MDTILE_METHOD_MOD) wgt = P.tile_w[toff] * P.rescale[(size_t)y * P.W + x];
 #pragma unroll
                         for (int pp = 0; pp < PP; ++pp) {
-                            if (pp >= np) continue;
                             const float v = to_f32<T>(src[(size_t)pp * tile_elems]);
-                            if (METHOD == MDTILE_METHOD_MOD) acc[pp][j] += v * wgt;
-                            else acc[pp][j] += v;
+                            if (METHOD == MDTILE_METHOD_MOD) a[pp] += v * wgt;
+                            else a[pp] += v;
                         }
                     }
+                }
+#pragma unroll
+                for (int pp = 0; pp < PP; ++pp) {  // acc[pp][j] = a[pp] without dynamic register indexing
+                    if (j == 0) acc[pp][0] = a[pp];
+                    else if (j == 1) acc[pp][1] = a[pp];
+                    else if (j == 2) acc[pp][2] = a[pp];
+                    else acc[pp][3] = a[pp];
                 }
             }
         }
@@ -180,7 +270,6 @@ __global__ __launch_bounds__(256) void k_blend(const BlendParams P) {
             const float wgt = METHOD == MDTILE_METHOD_MOD ? R.weight[off] : 1.0f;
 #pragma unroll
             for (int pp = 0; pp < PP; ++pp) {
-                if (pp >= np) continue;
                 const float v = to_f32<T>(src[(size_t)pp * rplane]);
                 if (METHOD == MDTILE_METHOD_MOD) acc[pp][j] += v * wgt;
                 else acc[pp][j] += v;
@@ -193,29 +282,30 @@ __global__ __launch_bounds__(256) void k_blend(const BlendParams P) {
     if (P.flags & MDTILE_BLEND_PARTIAL) {  // raw fp32 sums; the epilogue runs after the cross-rank sum
 #pragma unroll
         for (int pp = 0; pp < PP; ++pp) {
-            if (pp >= np) continue;
             float* dst = reinterpret_cast<float*>(P.out) + o + (size_t)pp * plane_px;
             if (nvalid == 4) store4<float>(dst, acc[pp]);
-            else for (int j = 0; j < nvalid; ++j) dst[j] = acc[pp][j];
+            else {
+                dst[0] = acc[pp][0];
+                if (nvalid > 1) dst[1] = acc[pp][1];
+                if (nvalid > 2) dst[2] = acc[pp][2];
+            }
         }
         return;
     }
 
     // MD normalisation: x = where(weights > 1, buf / weights, buf)  (multidiffusion.py:208); the weight is per pixel, shared by planes
-    if (METHOD == MDTILE_METHOD_MD) {
-        float w[4] = {1.f, 1.f, 1.f, 1.f};
-        if (nvalid == 4) load4<float>(P.weights + (size_t)y * P.W + x0, w);
-        else for (int j = 0; j < nvalid; ++j) w[j] = P.weights[(size_t)y * P.W + x0 + j];
+    if (METHOD == MDTILE_METHOD_MD && !(P.flags & MDT_DEBUG_SKIP_NORM)) {
 #pragma unroll
-        for (int pp = 0; pp < PP; ++pp)
+        for (int j = 0; j < 4; ++j) {
+            if (wq[j] > 1.0f) {   // correctly rounded division, only where upstream divides
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[pp][j] = w[j] > 1.0f ? acc[pp][j] / w[j] : acc[pp][j];
+                for (int pp = 0; pp < PP; ++pp) acc[pp][j] = acc[pp][j] / wq[j];
+            }
+        }
     }
 
     // foreground feather composite (multidiffusion.py:191-198, 211-216 == mixtureofdiffusers.py:154-161, 170-175)
-    bool any_fg = false;
-    for (int k = 0; k < P.num_regions; ++k) any_fg |= P.regions[k].mode == MDTILE_REGION_FG;
-    if (any_fg) {
+    if (P.num_fg > 0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (j >= nvalid) continue;
@@ -230,8 +320,7 @@ __global__ __launch_bounds__(256) void k_blend(const BlendParams P) {
                 const size_t rplane = (size_t)R.h * R.w, off = (size_t)ry * R.w + rx;
                 const T* src = reinterpret_cast<const T*>(R.out) + (size_t)p0 * rplane + off;
 #pragma unroll
-                for (int pp = 0; pp < PP; ++pp)
-                    if (pp < np) fbuf[pp] += to_f32<T>(src[(size_t)pp * rplane]);
+                for (int pp = 0; pp < PP; ++pp) fbuf[pp] += to_f32<T>(src[(size_t)pp * rplane]);
                 fmask += R.weight[off];
                 fcnt += 1.0f;
             }
@@ -249,10 +338,13 @@ __global__ __launch_bounds__(256) void k_blend(const BlendParams P) {
 
 #pragma unroll
     for (int pp = 0; pp < PP; ++pp) {
-        if (pp >= np) continue;
         T* dst = reinterpret_cast<T*>(P.out) + o + (size_t)pp * plane_px;
         if (nvalid == 4) store4<T>(dst, acc[pp]);
-        else for (int j = 0; j < nvalid; ++j) dst[j] = from_f32<T>(acc[pp][j]);
+        else {
+            dst[0] = from_f32<T>(acc[pp][0]);
+            if (nvalid > 1) dst[1] = from_f32<T>(acc[pp][1]);
+            if (nvalid > 2) dst[2] = from_f32<T>(acc[pp][2]);
+        }
     }
 }
 
@@ -318,6 +410,20 @@ __global__ __launch_bounds__(256) void k_gather_rect(const T* __restrict__ x_in,
     out[(size_t)plane * w * h + idx] = x_in[((size_t)plane * H + y0 + y) * W + x0 + x];
 }
 
+// (planes per thread, candidates per chunk).  PP must divide N*C; MDTILE_BLEND_CFG="PP,G" overrides the default (probing).
+template <typename T, int PP, int G>
+void launch_blend_cfg(const BlendParams& P, int method, hipStream_t s) {
+    dim3 grid(cdiv((long long)P.nrows * ((P.W + 3) / 4), 256), (P.N * P.C) / PP), block(256);
+    const bool packed = (P.flags & MDTILE_BLEND_PACKED) != 0;
+    if (method == MDTILE_METHOD_MD) {
+        if (packed) hipLaunchKernelGGL((k_blend<T, MDTILE_METHOD_MD, PP, G, true>), grid, block, 0, s, P);
+        else hipLaunchKernelGGL((k_blend<T, MDTILE_METHOD_MD, PP, G, false>), grid, block, 0, s, P);
+    } else {
+        if (packed) hipLaunchKernelGGL((k_blend<T, MDTILE_METHOD_MOD, PP, G, true>), grid, block, 0, s, P);
+        else hipLaunchKernelGGL((k_blend<T, MDTILE_METHOD_MOD, PP, G, false>), grid, block, 0, s, P);
+    }
+}
+
 template <typename T>
 int launch_blend(const BlendParams& P, int method, bool finalize, hipStream_t s) {
     dim3 block(256);
@@ -326,10 +432,24 @@ int launch_blend(const BlendParams& P, int method, bool finalize, hipStream_t s)
         if (method == MDTILE_METHOD_MD) hipLaunchKernelGGL((k_blend_finalize<T, MDTILE_METHOD_MD>), grid, block, 0, s, P);
         else hipLaunchKernelGGL((k_blend_finalize<T, MDTILE_METHOD_MOD>), grid, block, 0, s, P);
     } else {
-        constexpr int PP = 8;  // planes per thread: N*C = 8 for batch-1 CFG (cond + uncond) x 4 latent channels
-        dim3 grid(cdiv((long long)P.nrows * ((P.W + 3) / 4), 256), cdiv(P.N * P.C, PP));
-        if (method == MDTILE_METHOD_MD) hipLaunchKernelGGL((k_blend<T, MDTILE_METHOD_MD, PP>), grid, block, 0, s, P);
-        else hipLaunchKernelGGL((k_blend<T, MDTILE_METHOD_MOD, PP>), grid, block, 0, s, P);
+        const int planes = P.N * P.C;
+        // planes per thread: as many as keep >= ~128k threads in the grid (2 per lane of the chip), then G so that a
+        // thread has ~16 16-byte loads in flight (measured on MI355X: (8,2) for the 8K canvas, (4,4)/(2,4) below it)
+        const long long work = (long long)P.nrows * ((P.W + 3) / 4) * planes;
+        int pp = 8, g = 2;
+        while (pp > 1 && work / pp < 131072) pp >>= 1;
+        if (pp < 8) g = 4;
+        if (const char* e = getenv("MDTILE_BLEND_CFG")) {  // probing override; "0,0" keeps the heuristic
+            int epp = 0, eg = 0;
+            if (sscanf(e, "%d,%d", &epp, &eg) == 2 && epp > 0 && eg > 0) { pp = epp; g = eg; }
+        }
+        while (pp > 1 && planes % pp != 0) pp >>= 1;
+        if (pp >= 8 && g >= 4) launch_blend_cfg<T, 8, 4>(P, method, s);
+        else if (pp >= 8) launch_blend_cfg<T, 8, 2>(P, method, s);
+        else if (pp >= 4 && g >= 4) launch_blend_cfg<T, 4, 4>(P, method, s);
+        else if (pp >= 4) launch_blend_cfg<T, 4, 2>(P, method, s);
+        else if (pp >= 2) launch_blend_cfg<T, 2, 4>(P, method, s);
+        else launch_blend_cfg<T, 1, 4>(P, method, s);
     }
     MDT_LAUNCH_CHECK();
     return MDTILE_OK;
@@ -358,6 +478,7 @@ int fill_params(BlendParams& P, const mdtile_plan* p, const mdtile_blend_args* a
     }
     P.num_regions = num_regions; P.num_batches = num_batches;
     P.xs = p->d_xs; P.ys = p->d_ys; P.colrange = p->d_colrange; P.rowrange = p->d_rowrange;
+    P.colquad = p->d_colquad; P.rowinfo = p->d_rowinfo;
     P.weights = a->d_weights; P.tile_w = a->d_tile_w; P.rescale = a->d_rescale; P.out = a->d_x_out;
     if (a->method == MDTILE_METHOD_MD && !(a->flags & MDTILE_BLEND_PARTIAL))
         MDT_CHECK_ARG(a->d_weights, "mdtile_blend: MultiDiffusion needs d_weights");
@@ -371,6 +492,7 @@ int fill_params(BlendParams& P, const mdtile_plan* p, const mdtile_blend_args* a
         if (R.mode == MDTILE_REGION_FG || a->method == MDTILE_METHOD_MOD)
             MDT_CHECK_ARG(R.weight, "mdtile_blend: region %d needs a weight/feather map", k);
         P.regions[k] = R;
+        P.num_fg += R.mode == MDTILE_REGION_FG;
     }
     if (num_batches > 0) {
         MDT_CHECK_ARG(batch_out, "mdtile_blend: null batch_out");

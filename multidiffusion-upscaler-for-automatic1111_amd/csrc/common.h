@@ -6,6 +6,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/mdtile.h"
@@ -66,6 +67,18 @@ template <> __device__ __forceinline__ void load4<float>(const float* p, float (
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = t.v[j];
 }
+// 16-bit storage: 4 elements = one 8-byte access at 2-byte alignment
+struct __attribute__((packed, aligned(2))) u16x4_u { unsigned short v[4]; };
+template <> __device__ __forceinline__ void load4<__half>(const __half* p, float (&o)[4]) {
+    u16x4_u t = *reinterpret_cast<const u16x4_u*>(p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = __half2float(__ushort_as_half(t.v[j]));
+}
+template <> __device__ __forceinline__ void load4<__hip_bfloat16>(const __hip_bfloat16* p, float (&o)[4]) {
+    u16x4_u t = *reinterpret_cast<const u16x4_u*>(p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = __uint_as_float((unsigned)t.v[j] << 16);
+}
 template <typename T> __device__ __forceinline__ void store4(T* p, const float (&o)[4]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) p[j] = from_f32<T>(o[j]);
@@ -102,9 +115,14 @@ struct mdtile_plan {
     int tw, th, ov;           // effective tile size / overlap
     int cols, rows, T;
     int num_batches, tile_bs;
-    int* h_table;             // host block [xs | ys | colrange | rowrange]
+    int* h_table;             // host block [xs | ys | colrange | rowrange | pad | colquad | rowinfo]
     size_t table_len;
+    size_t quad_off;          // offset (ints, multiple of 4) of colquad inside the block; rowinfo follows it
     int *h_xs, *h_ys;         // views into h_table: [cols], [rows]
     int *d_xs, *d_ys;         // device mirror (lazy, see mdt::plan_upload)
     int *d_colrange, *d_rowrange;  // per canvas column/row: first covering tile index | (count << 16)
+    // 16-byte records for the blend kernel: ONE load gives a thread everything about its columns / its row
+    //   colquad[x/4] = { first | count << 16 of the tile columns covering ANY of the 4 px, xs[first], xs[first+1], xs[first+2] }
+    //   rowinfo[y]   = { first | count << 16 of the tile rows covering y,               ys[first], ys[first+1], ys[first+2] }
+    int4 *d_colquad, *d_rowinfo;
 };

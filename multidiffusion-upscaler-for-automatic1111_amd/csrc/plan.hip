@@ -83,14 +83,40 @@ extern "C" mdtile_plan* mdtile_plan_create(int w, int h, int tile_w, int tile_h,
     p->tile_bs = (p->T + p->num_batches - 1) / p->num_batches;
     // one host block [xs | ys | colrange | rowrange]; mirrored to the device lazily (mdt::plan_upload) so that the
     // integer planning works on a machine without a GPU.
-    p->table_len = xs.size() + ys.size() + cr.size() + rr.size();
-    p->h_table = new int[p->table_len];
+    const int W4 = (w + 3) / 4;
+    const size_t head = xs.size() + ys.size() + cr.size() + rr.size();
+    p->quad_off = (head + 3) & ~(size_t)3;
+    p->table_len = p->quad_off + 4 * (size_t)W4 + 4 * (size_t)h;
+    p->h_table = new int[p->table_len]();
     int* q = p->h_table;
     p->h_xs = q; memcpy(q, xs.data(), xs.size() * sizeof(int)); q += xs.size();
     p->h_ys = q; memcpy(q, ys.data(), ys.size() * sizeof(int)); q += ys.size();
     memcpy(q, cr.data(), cr.size() * sizeof(int)); q += cr.size();
     memcpy(q, rr.data(), rr.size() * sizeof(int));
+    // 16-byte records (see common.h).  A quad's candidate columns are the union over its (in-canvas) pixels; origins are
+    // non-decreasing and every pixel is covered, so the union is a contiguous index range.
+    auto origin3 = [](const std::vector<int>& org, int first, int k) { return first + k < (int)org.size() ? org[first + k] : 0; };
+    int* cq = p->h_table + p->quad_off;
+    for (int xq = 0; xq < W4; ++xq) {
+        int first = 1 << 30, last = -1;
+        for (int j = 0; j < 4 && 4 * xq + j < w; ++j) {
+            const int f = cr[4 * xq + j] & 0xffff, n = cr[4 * xq + j] >> 16;
+            if (n == 0) continue;
+            if (f < first) first = f;
+            if (f + n - 1 > last) last = f + n - 1;
+        }
+        if (last < 0) { first = 0; last = -1; }
+        cq[4 * xq + 0] = first | ((last - first + 1) << 16);
+        for (int k = 0; k < 3; ++k) cq[4 * xq + 1 + k] = origin3(xs, first, k);
+    }
+    int* ri = cq + 4 * (size_t)W4;
+    for (int y = 0; y < h; ++y) {
+        const int f = rr[y] & 0xffff;
+        ri[4 * y + 0] = rr[y];
+        for (int k = 0; k < 3; ++k) ri[4 * y + 1 + k] = origin3(ys, f, k);
+    }
     p->d_xs = p->d_ys = p->d_colrange = p->d_rowrange = nullptr;
+    p->d_colquad = p->d_rowinfo = nullptr;
     return p;
 }
 
@@ -107,6 +133,8 @@ int plan_upload(const mdtile_plan* cp) {
         return MDTILE_E_HIP;
     }
     p->d_xs = d; p->d_ys = d + p->cols; p->d_colrange = p->d_ys + p->rows; p->d_rowrange = p->d_colrange + p->w;
+    p->d_colquad = reinterpret_cast<int4*>(d + p->quad_off);          // hipMalloc is 256-B aligned, quad_off % 4 == 0
+    p->d_rowinfo = p->d_colquad + (p->w + 3) / 4;
     return MDTILE_OK;
 }
 }  // namespace mdt
