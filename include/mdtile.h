@@ -182,12 +182,15 @@ int mdtile_silu(const float* d_x, float* d_y, size_t n, mdtile_stream_t stream);
 int mdtile_add(const float* d_a, const float* d_b, float* d_y, size_t n, mdtile_stream_t stream);
 
 /* Conv tiles (queue tasks conv_in/conv1/conv2/nin_shortcut/upsample/conv_out/q/k/v/proj_out, tilevae.py:115-195).
- * stride 1, 'same' zero padding, ksize 1 or 3.  Weights are pre-packed once by mdtile_conv_pack (OIHW -> [tap][cin][cout]).
+ * stride 1, 'same' zero padding, ksize 1 or 3.  Weights are pre-packed once by mdtile_conv_pack (OIHW -> [tap][cin][cout] fp32,
+ * followed by the split-bf16 fragment-order image for the shapes the bf16x3 kernel takes; mdtile_conv_packed_size covers both).
  *   MDTILE_CONV_UPSAMPLE2X : input is read through a nearest 2x upsample (ldm Upsample: interpolate then conv)
  *   d_residual != NULL     : y = conv(x) + bias + residual   ('add_res' fused)
  *   out_layout             : 0 = [B,Cout,H,W];  1 = token-major [B,H*W,Cout] (V operand of mdtile_vae_attn)
  * H, W are the OUTPUT spatial size. */
 #define MDTILE_CONV_UPSAMPLE2X 1
+#define MDTILE_CONV_EXACT_F32 2   /* force the exact-fp32 MFMA kernel (default: split-bf16 "bf16x3" MFMA where the shape allows,
+                                     fp32 accumulate, ~1e-5 relative vs fp32; env MDTILE_CONV_MODE=f32 forces it globally) */
 size_t mdtile_conv_packed_size(int cout, int cin, int ksize); /* floats */
 int mdtile_conv_pack(const float* d_w_oihw, float* d_w_packed, int cout, int cin, int ksize, mdtile_stream_t stream);
 int mdtile_conv2d(const float* d_x, const float* d_w_packed, const float* d_bias, const float* d_residual, float* d_y,

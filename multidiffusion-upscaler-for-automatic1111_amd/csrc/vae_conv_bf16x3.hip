@@ -1,0 +1,305 @@
+// 3x3 conv tiles of the Tiled-VAE task queue on the bf16 matrix cores with SPLIT-fp32 operands ("bf16x3").
+//
+// Why: the decoder's 3x3 convs are ~70 % of an 8K decode and gfx950 has no TF32; exact-fp32 MFMA peaks at 157 TFLOP/s,
+// bf16 MFMA at 2.5 PFLOP/s.  Every fp32 operand is split x = hi + lo (hi = bf16(x), lo = bf16(x - hi): 16 significand
+// bits together) and a product is formed as  a_lo*b_hi + a_hi*b_lo + a_hi*b_hi  with fp32 accumulation inside the MFMA:
+// three bf16 MFMAs per fp32-class product = 16/3 x the fp32-MFMA rate.  The dropped a_lo*b_lo term and the split residue
+// are <= 2^-16 relative per product (measured end-to-end against the fp32 reference in tests/test_gpu_vae.py: ~1e-5, the
+// stated tolerance is 1e-3).  The exact-fp32 kernel (vae_conv.hip) stays available (MDTILE_CONV_EXACT_F32).
+//
+// Upstream call sites replaced: the nn.Conv2d tasks conv1 / conv2 / upsample.conv of scripts/tilevae.py:115-195 (+ the
+// queue's add_res, tilevae.py:614-616, and F.interpolate(nearest, 2x) of ldm's Upsample, both fused as in vae_conv.hip).
+//
+// GEMM view (implicit, no im2col):  D[cout][px] = sum_{tap, cin} W[cout][cin][tap] * X[cin][px + tap]
+//   MFMA v_mfma_f32_32x32x16_bf16:  A = weights (M = 32 couts, K = 16 cin of one tap), B = input (K = 16 cin, N = 32 px of a row)
+//   lane l supplies 8 consecutive k of row/col (l & 31): k-half (l >> 5)  ->  both operands want "8 channels of one
+//   cout / one pixel" as one 16-byte LDS record:
+//     input  LDS image  [hl][cg = 2][rows = 10][cols = 34] x 16 B   (cg = 8-channel group; halo tile of an 8 x 32 px block)
+//     weight LDS image  [hl][dx = 3][mtile][lane = 64]     x 16 B   (exactly the global pre-packed order: straight copy)
+//   every fragment read is one conflict-free ds_read_b128 (32 consecutive 16-byte records per half-wave).
+// Block = 512 threads = 8 waves (2 per SIMD), output tile BM couts x 8 rows x 32 px; wave = 64 couts x NROW rows.
+// K loop = phases (16-channel K-step, dy): 3 taps x (2 x NROW) tiles x 3 MFMAs per wave and phase, ONE barrier per phase;
+// the next phase's weights (24 KB, L2-resident) and the next K-step's input slab are fetched into registers at the start
+// of a phase and written to the other LDS stage at its end (fp32 -> hi/lo split happens on that write).
+#include "common.h"
+
+using namespace mdt;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // one 16-byte record (plain vector type: stays in registers)
+
+namespace {
+
+struct ConvBParams {
+    const float* x;      // [B, Cin, Hin, Win] fp32
+    const u32x4* w;      // packed bf16 hi/lo records, see k_conv_pack_bf16x3
+    const float* bias;   // [Cout] or null
+    const float* res;    // residual [B, Cout, H, W] or null
+    float* y;            // [B, Cout, H, W]
+    int B, Cin, Cout, H, W;   // H, W: OUTPUT spatial size
+    int Hin, Win, up;         // input spatial size; up = 1 for fused nearest-2x
+    int ptiles, PX, NCB, NK;  // pixel tiles, tiles per row, cout blocks, 16-channel K-steps
+};
+
+constexpr int TH = 8, TW = 32, ROWS = TH + 2, COLS = TW + 2;
+constexpr int IN_REC = 2 * ROWS * COLS;                 // 680 records (16 B) per hl per stage
+
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo) {
+    bf16x8 h, l;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        h[i] = (__bf16)v[i];                            // v_cvt_pk_bf16_f32 (RNE)
+        l[i] = (__bf16)(v[i] - (float)h[i]);            // exact residue, rounded once
+    }
+    hi = __builtin_bit_cast(u32x4, h);
+    lo = __builtin_bit_cast(u32x4, l);
+}
+
+template <int MT>  // 32-cout tiles per block: 4 (BM = 128) or 2 (BM = 64)
+__global__ __launch_bounds__(512) void k_conv3x3_bf16x3(const ConvBParams P) {
+    constexpr int BM = MT * 32;
+    constexpr int WAVES_M = MT / 2, WAVES_R = 8 / WAVES_M, NROW = TH / WAVES_R;
+    constexpr int W_REC = 2 * 3 * MT * 64;              // records per weight chunk (hi block then lo block)
+    constexpr int NWREG = (W_REC + 511) / 512;          // 3 (MT = 4) or 2 (MT = 2, half of the threads on the 2nd)
+    // LDS (16-byte records): input [2 stages][hl][IN_REC], weights [2 stages][W_REC]
+    constexpr int IN_STAGE = 2 * IN_REC;
+    __shared__ u32x4 smem[2 * IN_STAGE + 2 * W_REC];
+    u32x4* const in_l = smem;
+    u32x4* const w_l = smem + 2 * IN_STAGE;
+
+    // ---- block -> (pixel tile, cout block): XCD = id % 8 keeps all cout blocks of a pixel tile on one L2
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int ptile = (slot / P.NCB) * 8 + xcd, cb = slot % P.NCB;
+    if (ptile >= P.ptiles) return;
+    const int b = blockIdx.y;
+    const int py = ptile / P.PX, px = ptile - py * P.PX;
+    const int y0 = py * TH, x0 = px * TW;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kg = lane >> 5;
+    const int wm = wave % WAVES_M, wr = wave / WAVES_M;
+    const size_t HWin = (size_t)P.Hin * P.Win;
+    const float* xb = P.x + (size_t)b * P.Cin * HWin;
+
+    // ---- input staging map: record s = tid (+512) -> (cg, r, c); source offset inside a channel plane, valid flag
+    // (zero padding).  Loads are unconditional at a clamped address and zeroed by the flag: straight-line code.
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // provably wave-uniform
+    const bool has_rec1 = wave_u * 64 + 512 < IN_REC;          // 2nd record pass: only the first waves have records
+    int soff[2], scg[2];
+    float smask[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int s = tid + 512 * i;
+        if (s >= IN_REC) s = IN_REC - 1;                        // lanes past the end shadow the last record (never stored)
+        const int cg = s / (ROWS * COLS), p = s - cg * (ROWS * COLS);
+        const int r = p / COLS, c = p - r * COLS;
+        const int gy = y0 + r - 1, gx = x0 + c - 1;
+        const bool inside = gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
+        const int sy = P.up ? gy >> 1 : gy, sx = P.up ? gx >> 1 : gx;
+        scg[i] = cg;
+        soff[i] = inside ? sy * P.Win + sx : 0;
+        smask[i] = inside ? 1.0f : 0.0f;
+    }
+    float rin[2][8];
+    u32x4 rwt[NWREG];
+
+    auto load_input = [&](int k) {       // K-step k: channels 16k .. 16k+15
+        {
+            const float* src = xb + (size_t)(k * 16 + scg[0] * 8) * HWin + soff[0];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rin[0][j] = src[(size_t)j * HWin];
+        }
+        if (has_rec1) {
+            const float* src = xb + (size_t)(k * 16 + scg[1] * 8) * HWin + soff[1];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rin[1][j] = src[(size_t)j * HWin];
+        }
+    };
+    auto store_input = [&](int stage) {
+        u32x4* dst = in_l + stage * IN_STAGE;
+        {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = rin[0][j] * smask[0];
+            u32x4 hi, lo;
+            split8(v, hi, lo);
+            dst[tid] = hi;
+            dst[IN_REC + tid] = lo;
+        }
+        if (has_rec1) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = rin[1][j] * smask[1];
+            u32x4 hi, lo;
+            split8(v, hi, lo);
+            if (tid + 512 < IN_REC) {
+                dst[tid + 512] = hi;
+                dst[IN_REC + tid + 512] = lo;
+            }
+        }
+    };
+    const u32x4* wsrc = P.w + (size_t)cb * P.NK * 3 * W_REC;
+    auto load_weights = [&](int ph) {    // phase ph = k*3 + dy: one contiguous chunk of W_REC records
+        const u32x4* src = wsrc + (size_t)ph * W_REC;
+#pragma unroll
+        for (int i = 0; i < NWREG; ++i)
+            if (wave_u * 64 + 512 * i < W_REC) rwt[i] = src[tid + 512 * i];   // W_REC is a multiple of 64: whole waves
+    };
+    auto store_weights = [&](int stage) {
+        u32x4* dst = w_l + stage * W_REC;
+#pragma unroll
+        for (int i = 0; i < NWREG; ++i)
+            if (wave_u * 64 + 512 * i < W_REC) dst[tid + 512 * i] = rwt[i];
+    };
+
+    f32x16 acc[2][NROW];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NROW; ++n)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[m][n][q] = 0.0f;
+
+    const int nph = P.NK * 3;
+    load_input(0);
+    load_weights(0);
+    store_input(0);
+    store_weights(0);
+    __syncthreads();
+
+    for (int ph = 0; ph < nph; ++ph) {
+        const int k = ph / 3, dy = ph - 3 * k;
+        if (dy == 0 && k + 1 < P.NK) load_input(k + 1);
+        if (ph + 1 < nph) load_weights(ph + 1);
+
+        const u32x4* wst = w_l + (ph & 1) * W_REC;
+        const u32x4* ist = in_l + (k & 1) * IN_STAGE;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            bf16x8 a[2][2];   // [m][hl]
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl) {
+                    a[m][hl] = __builtin_bit_cast(bf16x8, wst[((hl * 3 + dx) * MT + wm * 2 + m) * 64 + lane]);
+                }
+#pragma unroll
+            for (int n = 0; n < NROW; ++n) {
+                const int rec = (kg * ROWS + wr * NROW + n + dy) * COLS + l31 + dx;
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, ist[rec]), bl = __builtin_bit_cast(bf16x8, ist[IN_REC + rec]);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], bh, acc[m][n], 0, 0, 0);   // w_lo * x_hi
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], bl, acc[m][n], 0, 0, 0);   // w_hi * x_lo
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], bh, acc[m][n], 0, 0, 0);   // w_hi * x_hi
+                }
+            }
+        }
+
+        if (ph + 1 < nph) store_weights((ph + 1) & 1);
+        if (dy == 2 && k + 1 < P.NK) store_input((k + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: + bias (+ residual), store NCHW.  C/D layout of a 32x32 MFMA: col = lane & 31, row = (q&3) + 8*(q>>2) + 4*(lane>>5)
+    // (128-byte runs along x per register).  All loads of a tile are issued before the first store.
+    const size_t HW = (size_t)P.H * P.W;
+    const int x = x0 + l31;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int cbase = cb * BM + (wm * 2 + m) * 32 + 4 * kg;
+        float bq[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int co = cbase + (q & 3) + 8 * (q >> 2);
+            bq[q] = P.bias ? P.bias[co < P.Cout ? co : P.Cout - 1] : 0.0f;
+        }
+#pragma unroll
+        for (int n = 0; n < NROW; ++n) {
+            const int y = y0 + wr * NROW + n;
+            if (y < P.H && x < P.W) {
+                const size_t o0 = ((size_t)b * P.Cout) * HW + (size_t)y * P.W + x;
+                float rq[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int co = cbase + (q & 3) + 8 * (q >> 2);
+                    rq[q] = P.res ? P.res[o0 + (size_t)(co < P.Cout ? co : P.Cout - 1) * HW] : 0.0f;
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int co = cbase + (q & 3) + 8 * (q >> 2);
+                    if (co < P.Cout) P.y[o0 + (size_t)co * HW] = acc[m][n][q] + bq[q] + rq[q];
+                }
+            }
+        }
+    }
+}
+
+// OIHW fp32 -> records [cb][k][dy][hl][dx][mt][lane] of 8 bf16:  cout = cb*BM + mt*32 + (lane & 31),
+// cin = k*16 + (lane >> 5)*8 + j,  tap = (dy, dx);  hl = 0: bf16(w), hl = 1: bf16(w - hi).  Zero outside [Cout) x [Cin).
+__global__ void k_conv_pack_bf16x3(const float* __restrict__ w, u32x4* __restrict__ out, int Cout, int Cin, int MT, int NCB, int NK) {
+    const size_t n = (size_t)NCB * NK * 3 * 2 * 3 * MT * 64;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    size_t r = i;
+    const int lane = (int)(r % 64); r /= 64;
+    const int mt = (int)(r % MT); r /= MT;
+    const int dx = (int)(r % 3); r /= 3;
+    const int hl = (int)(r % 2); r /= 2;
+    const int dy = (int)(r % 3); r /= 3;
+    const int k = (int)(r % NK); r /= NK;
+    const int cb = (int)r;
+    const int co = cb * MT * 32 + mt * 32 + (lane & 31);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ci = k * 16 + (lane >> 5) * 8 + j;
+        const float v = (co < Cout && ci < Cin) ? w[(((size_t)co * Cin + ci) * 3 + dy) * 3 + dx] : 0.0f;
+        const __bf16 h = (__bf16)v;
+        o[j] = hl == 0 ? h : (__bf16)(v - (float)h);
+    }
+    out[i] = __builtin_bit_cast(u32x4, o);
+}
+
+inline int round_up_i(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+
+namespace mdt {
+
+// shapes the split-bf16 3x3 kernel takes; everything else stays on the exact-fp32 kernel
+bool conv_bf16x3_eligible(int cout, int cin, int ksize) { return ksize == 3 && cin % 16 == 0 && cout >= 32; }
+static int conv_bf16x3_mt(int cout) { return cout > 64 ? 4 : 2; }
+
+size_t conv_bf16x3_packed_floats(int cout, int cin) {   // size of the record array in floats (4 per 16-byte record)
+    const int MT = conv_bf16x3_mt(cout), NCB = round_up_i(cout, MT * 32) / (MT * 32), NK = cin / 16;
+    return (size_t)NCB * NK * 3 * 2 * 3 * MT * 64 * 4;
+}
+
+int conv_bf16x3_pack(const float* d_w_oihw, void* d_out, int cout, int cin, hipStream_t s) {
+    const int MT = conv_bf16x3_mt(cout), NCB = round_up_i(cout, MT * 32) / (MT * 32), NK = cin / 16;
+    const size_t n = (size_t)NCB * NK * 3 * 2 * 3 * MT * 64;
+    hipLaunchKernelGGL(k_conv_pack_bf16x3, dim3(cdiv((long long)n, 256)), dim3(256), 0, s, d_w_oihw, (u32x4*)d_out, cout, cin, MT, NCB, NK);
+    MDT_LAUNCH_CHECK();
+    return MDTILE_OK;
+}
+
+int conv_bf16x3_launch(const float* d_x, const void* d_w_rec, const float* d_bias, const float* d_res, float* d_y, int B, int cin,
+                       int cout, int H, int W, int up, hipStream_t s) {
+    ConvBParams P;
+    P.x = d_x; P.w = (const u32x4*)d_w_rec; P.bias = d_bias; P.res = d_res; P.y = d_y;
+    P.B = B; P.Cin = cin; P.Cout = cout; P.H = H; P.W = W;
+    P.Hin = up ? H / 2 : H; P.Win = up ? W / 2 : W; P.up = up;
+    const int MT = conv_bf16x3_mt(cout);
+    P.PX = (W + TW - 1) / TW;
+    P.ptiles = P.PX * ((H + TH - 1) / TH);
+    P.NCB = round_up_i(cout, MT * 32) / (MT * 32);
+    P.NK = cin / 16;
+    dim3 grid(((P.ptiles + 7) / 8) * 8 * P.NCB, B), block(512);
+    if (MT == 4) hipLaunchKernelGGL(k_conv3x3_bf16x3<4>, grid, block, 0, s, P);
+    else hipLaunchKernelGGL(k_conv3x3_bf16x3<2>, grid, block, 0, s, P);
+    MDT_LAUNCH_CHECK();
+    return MDTILE_OK;
+}
+
+}  // namespace mdt

@@ -23,6 +23,7 @@ METHOD_MD, METHOD_MOD = 0, 1
 REGION_BG, REGION_FG = 0, 1
 BLEND_PARTIAL, BLEND_TILE_RANGE, BLEND_PACKED = 1, 2, 4
 CONV_UPSAMPLE2X = 1
+CONV_EXACT_F32 = 2
 MAX_BATCHES, MAX_REGIONS = 320, 16
 
 _DTYPES = {torch.float32: DT_F32, torch.float16: DT_F16, torch.bfloat16: DT_BF16}
@@ -435,7 +436,9 @@ class PackedConv:
         self.bias = None if bias is None else _dev_tensor(bias.detach().contiguous(), "bias", torch.float32)
 
     def __call__(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, upsample2x: bool = False,
-                 token_major: bool = False) -> torch.Tensor:
+                 token_major: bool = False, exact: bool = False) -> torch.Tensor:
+        """exact=True forces the exact-fp32 MFMA kernel; by default 3x3 convs with cin % 16 == 0 run on the split-bf16
+        ("bf16x3") matrix-core kernel: fp32 accumulate, ~1e-5 relative to fp32."""
         _dev_tensor(x, "x", torch.float32)
         B, cin, H, W = x.shape
         assert cin == self.cin, f"conv expects {self.cin} input channels, got {cin}"
@@ -447,7 +450,8 @@ class PackedConv:
             _dev_tensor(residual, "residual", torch.float32)
             assert residual.shape == y.shape
         _check(lib().mdtile_conv2d(_p(x), _p(self.packed), _p(self.bias), _p(residual), _p(y), B, self.cin, self.cout, H, W,
-                                   self.ksize, CONV_UPSAMPLE2X if upsample2x else 0, int(token_major), _stream()), "mdtile_conv2d")
+                                   self.ksize, (CONV_UPSAMPLE2X if upsample2x else 0) | (CONV_EXACT_F32 if exact else 0),
+                                   int(token_major), _stream()), "mdtile_conv2d")
         return y
 
 
