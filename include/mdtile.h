@@ -198,11 +198,15 @@ int mdtile_conv2d(const float* d_x, const float* d_w_packed, const float* d_bias
 
 /* attn_forward body between the 1x1 convs (tile_utils/attn.py:55-70): single head,
  * out[b,c,i] = sum_j v[b,c,j] * softmax_j(scale * sum_c' q[b,c',i] k[b,c',j]).
- * q,k: [B,C,T] channel-major;  v: [B,T,C] token-major (conv out_layout 1);  out: [B,C,T].  C multiple of 64.
- * d_ws: workspace of mdtile_vae_attn_ws_size(B,C,T) bytes. */
+ * q,k: [B,C,T] channel-major;  v: [B,T,C] token-major (conv out_layout 1);  out: [B,C,T].  C = 128, 256 or 512.
+ * Flash formulation (no T x T matrix).  Default: split-bf16 ("bf16x3") matrix-core kernel -- q, k, v and the
+ * probabilities are split into bf16 hi/lo pairs (16 significand bits), fp32 accumulation and fp32 softmax statistics,
+ * ~1e-5 relative to fp32; it stages fragment-order copies of q, k, v in d_ws (mdtile_vae_attn_ws_size(B,C,T) bytes).
+ * MDTILE_ATTN_EXACT_F32 (or env MDTILE_ATTN_MODE=f32) selects the exact-fp32 MFMA kernel, which needs no workspace. */
+#define MDTILE_ATTN_EXACT_F32 1
 size_t mdtile_vae_attn_ws_size(int B, int C, int T);
 int mdtile_vae_attn(const float* d_q, const float* d_k, const float* d_v, float* d_out, int B, int C, int T, float scale,
-                    void* d_ws, mdtile_stream_t stream);
+                    int flags, void* d_ws, mdtile_stream_t stream);
 
 /* crop_valid_region + result[...] = tile (tilevae.py:248-259, 630-632): copies the valid window of one finished tile
  * [N,C,th,tw] into result [N,C,RH,RW].  in_bbox/out_bbox as returned by mdtile_vae_split_tiles. */

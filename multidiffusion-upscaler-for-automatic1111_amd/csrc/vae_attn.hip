@@ -205,19 +205,37 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, const
 
 }  // namespace
 
+// vae_attn_bf16x3.hip
+namespace mdt {
+bool attn_bf16x3_eligible(int C);
+size_t attn_bf16x3_ws_bytes(int B, int C, int T);
+int attn_bf16x3_launch(const float* d_q, const float* d_k, const float* d_v_tok, float* d_out, int B, int C, int T, float scale, void* d_ws,
+                       hipStream_t s);
+}  // namespace mdt
+
+static bool attn_force_f32() {
+    static const bool f = [] { const char* e = getenv("MDTILE_ATTN_MODE"); return e && strcmp(e, "f32") == 0; }();
+    return f;
+}
+
+// the flash formulation keeps every intermediate on chip; the split-bf16 path needs room for the fragment-order
+// bf16 hi/lo images of q, k and v
 extern "C" size_t mdtile_vae_attn_ws_size(int B, int C, int T) {
-    (void)B; (void)C; (void)T;
-    return 0;  // the flash formulation keeps every intermediate on chip
+    if (B <= 0 || T <= 0 || !attn_bf16x3_eligible(C)) return 0;
+    return attn_bf16x3_ws_bytes(B, C, T);
 }
 
 extern "C" int mdtile_vae_attn(const float* d_q, const float* d_k, const float* d_v, float* d_out, int B, int C, int T, float scale,
-                               void* d_ws, mdtile_stream_t stream) {
-    (void)d_ws;
+                               int flags, void* d_ws, mdtile_stream_t stream) {
     MDT_CHECK_ARG(d_q && d_k && d_v && d_out, "mdtile_vae_attn: null argument");
     MDT_CHECK_ARG(B > 0 && B <= 65535 && T > 0, "mdtile_vae_attn: bad shape B=%d T=%d", B, T);
     MDT_CHECK_ARG(C == 128 || C == 256 || C == 512, "mdtile_vae_attn: C=%d unsupported (128, 256 or 512)", C);
-    dim3 grid((T + BM - 1) / BM, B), block(256);
     hipStream_t s = as_stream(stream);
+    if (!(flags & MDTILE_ATTN_EXACT_F32) && !attn_force_f32() && attn_bf16x3_eligible(C)) {
+        MDT_CHECK_ARG(d_ws, "mdtile_vae_attn: the split-bf16 path needs the workspace of mdtile_vae_attn_ws_size()");
+        return attn_bf16x3_launch(d_q, d_k, d_v, d_out, B, C, T, scale, d_ws, s);
+    }
+    dim3 grid((T + BM - 1) / BM, B), block(256);
     if (C == 512) hipLaunchKernelGGL(k_attn<4>, grid, block, 0, s, d_q, d_k, d_v, d_out, T, scale);
     else if (C == 256) hipLaunchKernelGGL(k_attn<2>, grid, block, 0, s, d_q, d_k, d_v, d_out, T, scale);
     else hipLaunchKernelGGL(k_attn<1>, grid, block, 0, s, d_q, d_k, d_v, d_out, T, scale);

@@ -1,0 +1,355 @@
+// Per-tile single-head self-attention of the VAE mid block on the bf16 matrix cores with SPLIT-fp32 operands ("bf16x3"),
+// flash style (the T x T score matrix never exists).  Same arithmetic contract as vae_conv_bf16x3.hip: every fp32 factor
+// is split x = hi + lo (two bf16, 16 significand bits), a product is x_lo*y_hi + x_hi*y_lo + x_hi*y_hi with fp32
+// accumulation inside the MFMA; softmax statistics and the exponentials stay fp32.
+// Upstream: tile_utils/attn.py:55-70 (bmm -> softmax -> bmm between the 1x1 convs).
+//
+// Two kernels:
+//   k_attn_prep_*   fp32 q, k ([B,C,T] channel-major) and v ([B,T,C] token-major)  ->  bf16 hi/lo FRAGMENT-ORDER records in
+//                   the workspace, padded with zeros to a multiple of 128 tokens, so that the main kernel's LDS stages
+//                   are straight 16-byte copies and every MFMA operand is one conflict-free ds_read_b128:
+//        Qrec / Krec [B][T128/32 token tiles][C/16 k-steps][hl][lane 64] x 8 bf16 :  token = 32*tile + (lane & 31),
+//                                                                                  channel = 16*ks + 8*(lane >> 5) + i
+//        Vrec        [B][T128/16 key groups ][C/32 m-tiles][hl][lane 64] x 8 bf16 :  channel = 32*mt + (lane & 31),
+//                                                       key = 16*group + (i & 3) + 8*(i >> 2) + 4*(lane >> 5)
+//                   The V key order is the order in which a lane of the TRANSPOSED score accumulator holds its keys, so
+//                   the probabilities go from the score MFMAs to the output MFMAs without any cross-lane movement.
+//   k_attn_bf16x3<C>  block = 512 threads (8 waves), 128 queries; per 128-key block:
+//        scores  St[key][query] = sum_c K[key][c] Q[query][c]   A = K (M = keys), B = Q (N = queries), K-dim = channels;
+//                wave w owns key tile w >> 1 and the two query tiles of half w & 1; channels stream in 32-channel slabs
+//        softmax a lane holds one query column (16 keys of its tile): max / sum in-lane + one 32-lane swap, the 4 key
+//                tiles of a query are combined through a few hundred bytes of LDS; P -> bf16 hi/lo records in LDS
+//        output  Ot[c][query] += sum_key V[key][c] P[key][query]   A = V^T (M = channels), B = P^T, K-dim = keys;
+//                the 128 x C output block lives in registers (8 waves x 8 accumulator tiles for C = 512)
+//   LDS: two 32 KB slab buffers (K+Q slabs, then V slabs; register-prefetched, ONE barrier per slab) + 64 KB P + statistics.
+#include "common.h"
+
+using namespace mdt;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BQ = 128, BK = 128;        // queries per block, keys per iteration
+constexpr int SLAB_REC = 2048;           // 16-byte records per slab buffer (32 KB)
+constexpr int P_REC = 8 * 4 * 2 * 64;    // [key k-step 8][query tile 4][hl][lane]
+constexpr int STAT_FLOATS = 4 * BQ + 4 * BQ + BQ;   // smax[4][128], ssum[4][128], alpha[128]
+
+__device__ __forceinline__ void split8v(const float (&v)[8], u32x4& hi, u32x4& lo) {
+    bf16x8 h, l;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        h[i] = (__bf16)v[i];
+        l[i] = (__bf16)(v[i] - (float)h[i]);
+    }
+    hi = __builtin_bit_cast(u32x4, h);
+    lo = __builtin_bit_cast(u32x4, l);
+}
+
+// ---- prep: q / k  [C][T] fp32 -> records [tile][ks][hl][lane]
+__global__ __launch_bounds__(256) void k_attn_prep_qk(const float* __restrict__ src, u32x4* __restrict__ dst, int C, int T, int tiles) {
+    const int NKS = C / 16;
+    const size_t n = (size_t)tiles * NKS * 64;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const int lane = (int)(idx & 63);
+    const int ks = (int)((idx >> 6) % NKS);
+    const int tile = (int)((idx >> 6) / NKS);
+    const int b = blockIdx.y;
+    const int tok = tile * 32 + (lane & 31);
+    const float* s = src + (size_t)b * C * T;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = ks * 16 + (lane >> 5) * 8 + i;
+        v[i] = tok < T ? s[(size_t)c * T + tok] : 0.0f;
+    }
+    u32x4 hi, lo;
+    split8v(v, hi, lo);
+    u32x4* d = dst + ((size_t)b * tiles * NKS + (size_t)tile * NKS + ks) * 128;
+    d[lane] = hi;
+    d[64 + lane] = lo;
+}
+
+// ---- prep: v  [T][C] fp32 token-major -> records [group16][mt][hl][lane]
+__global__ __launch_bounds__(256) void k_attn_prep_v(const float* __restrict__ src, u32x4* __restrict__ dst, int C, int T, int groups) {
+    const int NMT = C / 32;
+    const size_t n = (size_t)groups * NMT * 64;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const int lane = (int)(idx & 63);
+    const int mt = (int)((idx >> 6) % NMT);
+    const int g = (int)((idx >> 6) / NMT);
+    const int b = blockIdx.y;
+    const int c = mt * 32 + (lane & 31);
+    const float* s = src + (size_t)b * T * C;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int key = g * 16 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+        v[i] = key < T ? s[(size_t)key * C + c] : 0.0f;
+    }
+    u32x4 hi, lo;
+    split8v(v, hi, lo);
+    u32x4* d = dst + ((size_t)b * groups * NMT + (size_t)g * NMT + mt) * 128;
+    d[lane] = hi;
+    d[64 + lane] = lo;
+}
+
+template <int C>
+__global__ __launch_bounds__(512) void k_attn_bf16x3(const u32x4* __restrict__ Qr, const u32x4* __restrict__ Kr, const u32x4* __restrict__ Vr,
+                                                     float* __restrict__ out, int T, int T128, float scale) {
+    constexpr int NKS = C / 16, NMT = C / 32, NSS = NKS / 2;        // channel k-steps, 32-channel output tiles, score slabs
+    constexpr int WAVES_M = NMT < 8 ? NMT : 8, WAVES_N = 8 / WAVES_M, MT_W = NMT / WAVES_M, NT_W = 4 / WAVES_N;
+    constexpr int PV_REC = NMT * 2 * 64;                            // records of one V slab (16 keys)
+    constexpr int NVREG = (PV_REC + 511) / 512;
+    static_assert(PV_REC <= SLAB_REC && NSS >= 1, "slab sizing");
+    __shared__ u32x4 smem[2 * SLAB_REC + P_REC + STAT_FLOATS / 4];
+    u32x4* const slab = smem;
+    u32x4* const p_l = smem + 2 * SLAB_REC;
+    float* const smax = reinterpret_cast<float*>(smem + 2 * SLAB_REC + P_REC);
+    float* const ssum = smax + 4 * BQ;
+    float* const salpha = ssum + 4 * BQ;
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kg = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kt_w = wave >> 1, qh = wave & 1;                      // score phase: key tile, query-tile pair
+    const int wm = wave % WAVES_M, wn = wave / WAVES_M;             // output phase: channel tiles, query tiles
+    const int b = blockIdx.y, qb = blockIdx.x;
+    const int tiles = T128 / 32, groups = T128 / 16, nkb = T128 / BK;
+    const u32x4* Qb = Qr + (size_t)b * tiles * NKS * 128 + (size_t)qb * 4 * NKS * 128;
+    const u32x4* Kb = Kr + (size_t)b * tiles * NKS * 128;
+    const u32x4* Vb = Vr + (size_t)b * groups * NMT * 128;
+
+    u32x4 rg[4];
+    // score slab s of key block kb: records [K | Q][tile 4][ks 2][hl][lane]; source = 4 + 4 runs of 256 contiguous records
+    auto issue_S = [&](int kb, int s) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = tid + 512 * i;                 // i < 2: K part, i >= 2: Q part (compile-time)
+            const int rr = r & 1023, t4 = rr >> 8, off = rr & 255;
+            const u32x4* src = (i < 2 ? Kb + ((size_t)(kb * 4 + t4) * NKS + 2 * s) * 128 : Qb + ((size_t)t4 * NKS + 2 * s) * 128) + off;
+            rg[i] = *src;
+        }
+    };
+    auto issue_V = [&](int kb, int p) {
+        const u32x4* src = Vb + (size_t)(kb * 8 + p) * NMT * 128;
+#pragma unroll
+        for (int i = 0; i < NVREG; ++i)
+            if (wave * 64 + 512 * i < PV_REC) rg[i] = src[tid + 512 * i];
+    };
+    auto write_S = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) slab[buf * SLAB_REC + tid + 512 * i] = rg[i];
+    };
+    auto write_V = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NVREG; ++i)
+            if (wave * 64 + 512 * i < PV_REC) slab[buf * SLAB_REC + tid + 512 * i] = rg[i];
+    };
+
+    f32x16 acc_o[MT_W][NT_W];
+#pragma unroll
+    for (int m = 0; m < MT_W; ++m)
+#pragma unroll
+        for (int n = 0; n < NT_W; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_o[m][n][r] = 0.0f;
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.0f, 0.0f};   // for queries (2*qh + j)*32 + l31
+
+    int buf = 0;
+    issue_S(0, 0);
+    for (int kb = 0; kb < nkb; ++kb) {
+        // ------------------------------------------------ scores: St tiles (kt_w, 2*qh + j), all channels
+        f32x16 st[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[j][r] = 0.0f;
+#pragma unroll 1
+        for (int s = 0; s < NSS; ++s) {
+            write_S(buf);
+            __syncthreads();
+            if (s + 1 < NSS) issue_S(kb, s + 1);
+            else issue_V(kb, 0);
+            const u32x4* sl = slab + buf * SLAB_REC;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, sl[((kt_w * 2 + ks) * 2 + 0) * 64 + lane]);
+                const bf16x8 al = __builtin_bit_cast(bf16x8, sl[((kt_w * 2 + ks) * 2 + 1) * 64 + lane]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int qt = 2 * qh + j;
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, sl[1024 + ((qt * 2 + ks) * 2 + 0) * 64 + lane]);
+                    const bf16x8 bl = __builtin_bit_cast(bf16x8, sl[1024 + ((qt * 2 + ks) * 2 + 1) * 64 + lane]);
+                    st[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, st[j], 0, 0, 0);
+                    st[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, st[j], 0, 0, 0);
+                    st[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, st[j], 0, 0, 0);
+                }
+            }
+            buf ^= 1;
+        }
+        // ------------------------------------------------ online softmax (lane = query column, 16 keys of tile kt_w per j)
+        const int key0 = kb * BK + kt_w * 32 + 4 * kg;
+        float mx[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = key0 + (r & 3) + 8 * (r >> 2);
+                const float sv = key < T ? st[j][r] * scale : -INFINITY;
+                st[j][r] = sv;
+                m = fmaxf(m, sv);
+            }
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            mx[j] = m;
+            if (kg == 0) smax[kt_w * BQ + (2 * qh + j) * 32 + l31] = m;
+        }
+        __syncthreads();
+        float alpha[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = (2 * qh + j) * 32 + l31;
+            const float m_blk = fmaxf(fmaxf(smax[q], smax[BQ + q]), fmaxf(smax[2 * BQ + q], smax[3 * BQ + q]));
+            const float m_new = fmaxf(m_run[j], m_blk);      // finite: every key block holds >= 1 valid key
+            alpha[j] = expf(m_run[j] - m_new);               // exp(-inf) = 0 on the first block
+            m_run[j] = m_new;
+            float ps = 0.0f;
+            float pv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                pv[r] = expf(st[j][r] - m_new);              // masked keys: exp(-inf) = 0
+                ps += pv[r];
+            }
+            ps += __shfl_xor(ps, 32, 64);
+            if (kg == 0) {
+                ssum[kt_w * BQ + q] = ps;
+                if (kt_w == 0) salpha[q] = alpha[j];
+            }
+            // P records for the output MFMAs: k-step (kt_w*2 + s2) of this key block, query tile 2*qh + j.
+            // register r = 8*s2 + i  <->  key 16*s2 + (i & 3) + 8*(i >> 2) + 4*kg of the tile == the Vrec key order.
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float v8[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v8[i] = pv[8 * s2 + i];
+                u32x4 hi, lo;
+                split8v(v8, hi, lo);
+                u32x4* d = p_l + (((kt_w * 2 + s2) * 4 + (2 * qh + j)) * 2) * 64;
+                d[lane] = hi;
+                d[64 + lane] = lo;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = (2 * qh + j) * 32 + l31;
+            l_run[j] = l_run[j] * alpha[j] + ((ssum[q] + ssum[BQ + q]) + (ssum[2 * BQ + q] + ssum[3 * BQ + q]));
+        }
+        // ------------------------------------------------ output: rescale, then Ot += V^T P^T over the 128 keys
+#pragma unroll
+        for (int n = 0; n < NT_W; ++n) {
+            const float a = salpha[(wn * NT_W + n) * 32 + l31];
+#pragma unroll
+            for (int m = 0; m < MT_W; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_o[m][n][r] *= a;
+        }
+#pragma unroll 1
+        for (int p = 0; p < 8; ++p) {
+            write_V(buf);
+            __syncthreads();
+            if (p + 1 < 8) issue_V(kb, p + 1);
+            else if (kb + 1 < nkb) issue_S(kb + 1, 0);
+            const u32x4* sl = slab + buf * SLAB_REC;
+            bf16x8 vh[MT_W], vl[MT_W];
+#pragma unroll
+            for (int m = 0; m < MT_W; ++m) {
+                vh[m] = __builtin_bit_cast(bf16x8, sl[((wm * MT_W + m) * 2 + 0) * 64 + lane]);
+                vl[m] = __builtin_bit_cast(bf16x8, sl[((wm * MT_W + m) * 2 + 1) * 64 + lane]);
+            }
+#pragma unroll
+            for (int n = 0; n < NT_W; ++n) {
+                const u32x4* pr = p_l + ((p * 4 + wn * NT_W + n) * 2) * 64;
+                const bf16x8 ph = __builtin_bit_cast(bf16x8, pr[lane]);
+                const bf16x8 pl = __builtin_bit_cast(bf16x8, pr[64 + lane]);
+#pragma unroll
+                for (int m = 0; m < MT_W; ++m) {
+                    acc_o[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl[m], ph, acc_o[m][n], 0, 0, 0);
+                    acc_o[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[m], pl, acc_o[m][n], 0, 0, 0);
+                    acc_o[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[m], ph, acc_o[m][n], 0, 0, 0);
+                }
+            }
+            buf ^= 1;
+        }
+    }
+
+    // ---------------------------------------------------- normalise by the softmax denominator and store [B, C, T]
+    __syncthreads();
+    if (kt_w == 0 && kg == 0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ssum[(2 * qh + j) * 32 + l31] = l_run[j];
+    }
+    __syncthreads();
+    float* ob = out + (size_t)b * C * T;
+#pragma unroll
+    for (int n = 0; n < NT_W; ++n) {
+        const int ql = (wn * NT_W + n) * 32 + l31;
+        const int q = qb * BQ + ql;
+        const float inv = 1.0f / ssum[ql];
+        if (q < T) {
+#pragma unroll
+            for (int m = 0; m < MT_W; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = (wm * MT_W + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                    ob[(size_t)c * T + q] = acc_o[m][n][r] * inv;
+                }
+        }
+    }
+}
+
+}  // namespace
+
+namespace mdt {
+
+bool attn_bf16x3_eligible(int C) { return C == 128 || C == 256 || C == 512; }
+
+// workspace: Qrec, Krec, Vrec, each B * T128 * C * 4 bytes (hi + lo bf16 per element)
+size_t attn_bf16x3_ws_bytes(int B, int C, int T) {
+    const size_t T128 = ((size_t)T + 127) / 128 * 128;
+    return 3 * (size_t)B * T128 * C * 4;
+}
+
+int attn_bf16x3_launch(const float* d_q, const float* d_k, const float* d_v_tok, float* d_out, int B, int C, int T, float scale, void* d_ws,
+                       hipStream_t s) {
+    const int T128 = (T + 127) / 128 * 128;
+    const size_t per = (size_t)B * T128 * C * 4 / 16;   // records per operand
+    u32x4* Qr = (u32x4*)d_ws;
+    u32x4* Kr = Qr + per;
+    u32x4* Vr = Kr + per;
+    const int tiles = T128 / 32, groups = T128 / 16;
+    {
+        const size_t n = (size_t)tiles * (C / 16) * 64;
+        dim3 grid(cdiv((long long)n, 256), B);
+        hipLaunchKernelGGL(k_attn_prep_qk, grid, dim3(256), 0, s, d_q, Qr, C, T, tiles);
+        hipLaunchKernelGGL(k_attn_prep_qk, grid, dim3(256), 0, s, d_k, Kr, C, T, tiles);
+    }
+    {
+        const size_t n = (size_t)groups * (C / 32) * 64;
+        dim3 grid(cdiv((long long)n, 256), B);
+        hipLaunchKernelGGL(k_attn_prep_v, grid, dim3(256), 0, s, d_v_tok, Vr, C, T, groups);
+    }
+    MDT_LAUNCH_CHECK();
+    dim3 grid(T128 / BQ, B), block(512);
+    if (C == 512) hipLaunchKernelGGL(k_attn_bf16x3<512>, grid, block, 0, s, Qr, Kr, Vr, d_out, T, T128, scale);
+    else if (C == 256) hipLaunchKernelGGL(k_attn_bf16x3<256>, grid, block, 0, s, Qr, Kr, Vr, d_out, T, T128, scale);
+    else hipLaunchKernelGGL(k_attn_bf16x3<128>, grid, block, 0, s, Qr, Kr, Vr, d_out, T, T128, scale);
+    MDT_LAUNCH_CHECK();
+    return MDTILE_OK;
+}
+
+}  // namespace mdt

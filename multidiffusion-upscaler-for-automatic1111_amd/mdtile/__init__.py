@@ -24,6 +24,7 @@ REGION_BG, REGION_FG = 0, 1
 BLEND_PARTIAL, BLEND_TILE_RANGE, BLEND_PACKED = 1, 2, 4
 CONV_UPSAMPLE2X = 1
 CONV_EXACT_F32 = 2
+ATTN_EXACT_F32 = 1
 MAX_BATCHES, MAX_REGIONS = 320, 16
 
 _DTYPES = {torch.float32: DT_F32, torch.float16: DT_F16, torch.bfloat16: DT_BF16}
@@ -78,7 +79,7 @@ _SIGNATURES = {
     "mdtile_conv2d": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                               c_int, c_int, c_void_p]),
     "mdtile_vae_attn_ws_size": (c_size_t, [c_int, c_int, c_int]),
-    "mdtile_vae_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "mdtile_vae_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p]),
     "mdtile_crop_store": (c_int, [c_void_p, c_int, c_int, c_int, c_int, _IP, _IP, c_int, c_void_p, c_int, c_int, c_void_p]),
     "mdtile_vae_fast_size": (c_int, [c_int, c_int, c_int, _IP, _IP]),
     "mdtile_vae_fast_ws_size": (c_size_t, [c_int]),
@@ -455,17 +456,19 @@ class PackedConv:
         return y
 
 
-def vae_attn(q: torch.Tensor, k: torch.Tensor, v_tok: torch.Tensor, scale: float) -> torch.Tensor:
-    """Single-head attention core (tile_utils/attn.py:55-70).  q,k: [B,C,T]; v_tok: [B,T,C]; returns [B,C,T]."""
+def vae_attn(q: torch.Tensor, k: torch.Tensor, v_tok: torch.Tensor, scale: float, exact: bool = False) -> torch.Tensor:
+    """Single-head attention core (tile_utils/attn.py:55-70).  q,k: [B,C,T]; v_tok: [B,T,C]; returns [B,C,T].
+    Default: split-bf16 matrix-core flash kernel (fp32 accumulate / softmax, ~1e-5 relative); exact=True: fp32 MFMA."""
     _dev_tensor(q, "q", torch.float32)
     _dev_tensor(k, "k", torch.float32)
     _dev_tensor(v_tok, "v", torch.float32)
     B, C, T = q.shape
     assert k.shape == q.shape and tuple(v_tok.shape) == (B, T, C)
     out = torch.empty_like(q)
-    ws_bytes = lib().mdtile_vae_attn_ws_size(B, C, T)
+    ws_bytes = 0 if exact else lib().mdtile_vae_attn_ws_size(B, C, T)
     ws = torch.empty(max(1, (ws_bytes + 3) // 4), dtype=torch.float32, device=q.device)
-    _check(lib().mdtile_vae_attn(_p(q), _p(k), _p(v_tok), _p(out), B, C, T, scale, _p(ws), _stream()), "mdtile_vae_attn")
+    _check(lib().mdtile_vae_attn(_p(q), _p(k), _p(v_tok), _p(out), B, C, T, scale, ATTN_EXACT_F32 if exact else 0, _p(ws), _stream()),
+           "mdtile_vae_attn")
     return out
 
 

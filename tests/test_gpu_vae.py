@@ -106,20 +106,24 @@ def test_conv2d_vs_torch(plugin, cuda, B, cin, cout, k, H, W, up, res, tok, exac
     assert err < tol, f"conv rel err {err}; worst at {np.unravel_index((out - ref).abs().argmax().item(), ref.shape)}"
 
 
-@pytest.mark.parametrize("B,C,T", [(1, 128, 64), (1, 128, 100), (2, 128, 200), (1, 256, 77), (1, 512, 150), (1, 512, 1000)])
-def test_attention_vs_oracle(plugin, cuda, B, C, T):
+@pytest.mark.parametrize("exact", [False, True], ids=["bf16x3", "f32"])
+@pytest.mark.parametrize("B,C,T", [(1, 128, 64), (1, 128, 100), (2, 128, 200), (1, 256, 77), (1, 512, 150), (1, 512, 1000),
+                                   (1, 512, 128), (2, 256, 513), (1, 128, 2050)])
+def test_attention_vs_oracle(plugin, cuda, B, C, T, exact):
     E = plugin.engine
     torch.manual_seed(C + T)
     q, k, v = torch.randn(B, C, T), torch.randn(B, C, T) * 1.5, torch.randn(B, C, T)
     scale = float(int(C) ** (-0.5))
     w_ = torch.softmax(torch.bmm(q.permute(0, 2, 1), k) * scale, dim=2)          # attn.py:57-60
     ref = torch.bmm(v, w_.permute(0, 2, 1))                                        # attn.py:63-66
-    out = E.vae_attn(q.to(cuda), k.to(cuda), v.permute(0, 2, 1).contiguous().to(cuda), scale).cpu()
+    out = E.vae_attn(q.to(cuda), k.to(cuda), v.permute(0, 2, 1).contiguous().to(cuda), scale, exact=exact).cpu()
     err = _rel(out, ref)
-    assert err < 2e-5, f"attention rel err {err}"
+    # exact: fp32 MFMA.  Default: split-bf16 operands (16 significand bits per factor), fp32 accumulation + softmax.
+    assert err < (2e-5 if exact else 1e-4), f"attention rel err {err}"
 
 
-def test_attention_online_softmax_rescale_branch(plugin, cuda):
+@pytest.mark.parametrize("exact", [False, True], ids=["bf16x3", "f32"])
+def test_attention_online_softmax_rescale_branch(plugin, cuda, exact):
     """Force the running-max update late in the key sequence (a spike in the last key block) -- bounded random data alone
     never exercises a wrong rescale."""
     E = plugin.engine
@@ -131,8 +135,8 @@ def test_attention_online_softmax_rescale_branch(plugin, cuda):
     scale = float(C ** -0.5)
     w_ = torch.softmax(torch.bmm(q.permute(0, 2, 1), k) * scale, dim=2)
     ref = torch.bmm(v, w_.permute(0, 2, 1))
-    out = E.vae_attn(q.to(cuda), k.to(cuda), v.permute(0, 2, 1).contiguous().to(cuda), scale).cpu()
-    assert _rel(out, ref) < 2e-5
+    out = E.vae_attn(q.to(cuda), k.to(cuda), v.permute(0, 2, 1).contiguous().to(cuda), scale, exact=exact).cpu()
+    assert _rel(out, ref) < (2e-5 if exact else 1e-4)
 
 
 def test_attn_block_golden(plugin, cuda, golden_vae):
@@ -145,7 +149,7 @@ def test_attn_block_golden(plugin, cuda, golden_vae):
         ref = vo.attn_body(ab, hx)
     pack = plugin.tilevae.AttnPack(ab.to(cuda))
     out = pack(hx.to(cuda), torch.zeros_like(hx).to(cuda)).cpu()
-    assert _rel(out, ref) < 2e-5
+    assert _rel(out, ref) < 1e-4
 
 
 def test_crop_store_and_fast_input(plugin, cuda):
