@@ -35,6 +35,9 @@ for _p in (ROOT, PLUGIN):
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
+# split-bf16 kernels issue 3 bf16 MFMAs per fp32-class product: their ceiling in ALGORITHMIC (fp32-equivalent) flops
+MFMA_BF16X3_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 3.0
 
 
 def parse():
@@ -257,8 +260,13 @@ def main():
             dom = max(conv_tags, key=lambda k_: conv_tags[k_][2])
             n, work, secs = conv_tags[dom]
             ach = work / secs / 1e12
-            roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None, "launches": n,
+            # which matrix-core path the dominant kernel ran on: 3x3 convs with cin % 16 == 0 and attention use the
+            # split-bf16 kernels unless MDTILE_CONV_MODE=f32 / the exact flag is set; 1x1 convs and narrow convs are fp32 MFMA
+            bf16x3 = os.environ.get("MDTILE_CONV_MODE", "") != "f32" and dom in ("conv3x3_wide", "attn")
+            peak = MFMA_BF16X3_PEAK_TFLOPS if bf16x3 else MFMA_F32_PEAK_TFLOPS
+            roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                        "frac": round(ach / peak, 4), "traffic": None, "launches": n,
+                        "mfma_path": "bf16x3 (3 bf16 MFMAs per fp32-class product; peak = 2500/3 algorithmic TFLOP/s)" if bf16x3 else "fp32 MFMA",
                         "avg_us": round(secs / n * 1e6, 1), "flops_per_launch": work / n,
                         "breakdown_s": {k: round(v[2], 4) for k, v in sorted(agg.items())},
                         "breakdown_tflops": {k: round(v[1] / v[2] / 1e12, 2) for k, v in sorted(conv_tags.items())}}
@@ -324,7 +332,7 @@ def main():
         out = {
             "metric": "latent-px/sec tile-blend+VAE-decode, 8K image", "value": round(value, 1), "unit": "latent-px/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32" if os.environ.get("MDTILE_CONV_MODE", "") == "f32" else "bf16x3+f32", "data": "synthetic",
             "config": {"workload": f"SDXL 8192x8192 (latent {L}x{L}): {args.evals} x [tile gather + {'MultiDiffusion' if args.method == 'md' else 'Mixture-of-Diffusers'} "
                                    f"blend, {plan.num_tiles} tiles {plan.tile_w}x{plan.tile_h} overlap {plan.overlap}, N=2,C=4] + "
                                    + ("no VAE" if hook is None else f"tiled VAE decode (tile {args.vae_tile}, {'slow' if args.slow_vae else 'fast'} mode, SD decoder ch=128, random weights)"),

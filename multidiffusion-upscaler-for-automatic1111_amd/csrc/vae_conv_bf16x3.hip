@@ -56,14 +56,16 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo
     lo = __builtin_bit_cast(u32x4, l);
 }
 
-template <int MT>  // 32-cout tiles per block: 4 (BM = 128) or 2 (BM = 64)
+template <int MT, int TH_>  // MT: 32-cout tiles per block, 4 (BM = 128) or 2 (BM = 64); TH_: pixel rows per block, 8 or 16
 __global__ __launch_bounds__(512) void k_conv3x3_bf16x3(const ConvBParams P) {
     constexpr int BM = MT * 32;
-    constexpr int WAVES_M = MT / 2, WAVES_R = 8 / WAVES_M, NROW = TH / WAVES_R;
+    constexpr int WAVES_M = MT / 2, WAVES_R = 8 / WAVES_M, NROW = TH_ / WAVES_R;
+    constexpr int ROWS_ = TH_ + 2, IN_REC_ = 2 * ROWS_ * COLS;   // halo tile records per hl per stage
+    constexpr int NPASS = (IN_REC_ + 511) / 512;                  // staging passes of the 512 threads
     constexpr int W_REC = 2 * 3 * MT * 64;              // records per weight chunk (hi block then lo block)
     constexpr int NWREG = (W_REC + 511) / 512;          // 3 (MT = 4) or 2 (MT = 2, half of the threads on the 2nd)
-    // LDS (16-byte records): input [2 stages][hl][IN_REC], weights [2 stages][W_REC]
-    constexpr int IN_STAGE = 2 * IN_REC;
+    // LDS (16-byte records): input [2 stages][hl][IN_REC_], weights [2 stages][W_REC]
+    constexpr int IN_STAGE = 2 * IN_REC_;
     __shared__ u32x4 smem[2 * IN_STAGE + 2 * W_REC];
     u32x4* const in_l = smem;
     u32x4* const w_l = smem + 2 * IN_STAGE;
@@ -74,24 +76,23 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16x3(const ConvBParams P) {
     if (ptile >= P.ptiles) return;
     const int b = blockIdx.y;
     const int py = ptile / P.PX, px = ptile - py * P.PX;
-    const int y0 = py * TH, x0 = px * TW;
+    const int y0 = py * TH_, x0 = px * TW;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kg = lane >> 5;
     const int wm = wave % WAVES_M, wr = wave / WAVES_M;
     const size_t HWin = (size_t)P.Hin * P.Win;
     const float* xb = P.x + (size_t)b * P.Cin * HWin;
 
-    // ---- input staging map: record s = tid (+512) -> (cg, r, c); source offset inside a channel plane, valid flag
+    // ---- input staging map: record s = tid + 512 i -> (cg, r, c); source offset inside a channel plane, valid flag
     // (zero padding).  Loads are unconditional at a clamped address and zeroed by the flag: straight-line code.
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // provably wave-uniform
-    const bool has_rec1 = wave_u * 64 + 512 < IN_REC;          // 2nd record pass: only the first waves have records
-    int soff[2], scg[2];
-    float smask[2];
+    int soff[NPASS], scg[NPASS];
+    float smask[NPASS];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NPASS; ++i) {
         int s = tid + 512 * i;
-        if (s >= IN_REC) s = IN_REC - 1;                        // lanes past the end shadow the last record (never stored)
-        const int cg = s / (ROWS * COLS), p = s - cg * (ROWS * COLS);
+        if (s >= IN_REC_) s = IN_REC_ - 1;                      // lanes past the end shadow the last record (never stored)
+        const int cg = s / (ROWS_ * COLS), p = s - cg * (ROWS_ * COLS);
         const int r = p / COLS, c = p - r * COLS;
         const int gy = y0 + r - 1, gx = x0 + c - 1;
         const bool inside = gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
@@ -100,41 +101,33 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16x3(const ConvBParams P) {
         soff[i] = inside ? sy * P.Win + sx : 0;
         smask[i] = inside ? 1.0f : 0.0f;
     }
-    float rin[2][8];
+    float rin[NPASS][8];
     u32x4 rwt[NWREG];
 
     auto load_input = [&](int k) {       // K-step k: channels 16k .. 16k+15
-        {
-            const float* src = xb + (size_t)(k * 16 + scg[0] * 8) * HWin + soff[0];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) rin[0][j] = src[(size_t)j * HWin];
-        }
-        if (has_rec1) {
-            const float* src = xb + (size_t)(k * 16 + scg[1] * 8) * HWin + soff[1];
+        for (int i = 0; i < NPASS; ++i) {
+            if (wave_u * 64 + 512 * i < IN_REC_) {               // whole waves past the end of the record list skip the pass
+                const float* src = xb + (size_t)(k * 16 + scg[i] * 8) * HWin + soff[i];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) rin[1][j] = src[(size_t)j * HWin];
+                for (int j = 0; j < 8; ++j) rin[i][j] = src[(size_t)j * HWin];
+            }
         }
     };
     auto store_input = [&](int stage) {
         u32x4* dst = in_l + stage * IN_STAGE;
-        {
-            float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = rin[0][j] * smask[0];
-            u32x4 hi, lo;
-            split8(v, hi, lo);
-            dst[tid] = hi;
-            dst[IN_REC + tid] = lo;
-        }
-        if (has_rec1) {
-            float v[8];
+        for (int i = 0; i < NPASS; ++i) {
+            if (wave_u * 64 + 512 * i < IN_REC_) {
+                float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = rin[1][j] * smask[1];
-            u32x4 hi, lo;
-            split8(v, hi, lo);
-            if (tid + 512 < IN_REC) {
-                dst[tid + 512] = hi;
-                dst[IN_REC + tid + 512] = lo;
+                for (int j = 0; j < 8; ++j) v[j] = rin[i][j] * smask[i];
+                u32x4 hi, lo;
+                split8(v, hi, lo);
+                if (tid + 512 * i < IN_REC_) {
+                    dst[tid + 512 * i] = hi;
+                    dst[IN_REC_ + tid + 512 * i] = lo;
+                }
             }
         }
     };
@@ -185,8 +178,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16x3(const ConvBParams P) {
                 }
 #pragma unroll
             for (int n = 0; n < NROW; ++n) {
-                const int rec = (kg * ROWS + wr * NROW + n + dy) * COLS + l31 + dx;
-                const bf16x8 bh = __builtin_bit_cast(bf16x8, ist[rec]), bl = __builtin_bit_cast(bf16x8, ist[IN_REC + rec]);
+                const int rec = (kg * ROWS_ + wr * NROW + n + dy) * COLS + l31 + dx;
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, ist[rec]), bl = __builtin_bit_cast(bf16x8, ist[IN_REC_ + rec]);
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], bh, acc[m][n], 0, 0, 0);   // w_lo * x_hi
@@ -261,6 +254,242 @@ __global__ void k_conv_pack_bf16x3(const float* __restrict__ w, u32x4* __restric
     out[i] = __builtin_bit_cast(u32x4, o);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused nearest-2x upsample + 3x3 conv as FOUR 2x2 convs on the un-upsampled input ("sub-pixel" form): 2.25x fewer MACs.
+//
+// ldm's Upsample is F.interpolate(x, 2.0, 'nearest') followed by a 3x3 'same' conv (the queue's upsample.conv task,
+// scripts/tilevae.py:139-153).  up[i][j] = in[i >> 1][j >> 1], so for output pixel (2y + a, 2x + b), a, b in {0, 1}, the
+// three up-rows 2y+a-1 .. 2y+a+1 land on only TWO input rows:
+//     a = 0:  rows {y-1, y, y}   ->  tap u=0 = w[dy=0] on row y-1,        tap u=1 = w[dy=1] + w[dy=2] on row y
+//     a = 1:  rows {y, y, y+1}   ->  tap u=0 = w[dy=0] + w[dy=1] on row y, tap u=1 = w[dy=2] on row y+1
+// i.e. input row offset = a + u - 1; columns alike with (b, v).  Zero padding is preserved exactly: up-row -1 <-> input
+// row -1 and up-row 2H <-> input row H are the only out-of-range taps and the merged taps never straddle the border.
+// The merged weights are summed in fp32 once at pack time (k_upconv_pack_bf16x3), then hi/lo split like the others.
+//
+// Block = 512 threads, BM couts x (8 x 32 INPUT px) = 16 x 64 output px of ONE row parity a (blockIdx carries a) and BOTH
+// column parities: the accumulators of b = 0 and b = 1 sit in the same lane, so the epilogue stores float2 (x = 2X, 2X+1).
+// K loop = phases (16-channel K-step, u): column shifts s = b + v in {0, 1, 2} share their input fragments between the
+// parities -> per phase and wave 3 x NROW x 2 input + 4 x 2 x 2 weight fragment reads feed 4 x 2 x NROW x 3 MFMAs.
+template <int MT>
+__global__ __launch_bounds__(512) void k_upconv_bf16x3(const ConvBParams P) {
+    constexpr int BM = MT * 32;
+    constexpr int WAVES_M = MT / 2, WAVES_R = 8 / WAVES_M, NROW = TH / WAVES_R;
+    constexpr int W_REC = 2 * 2 * 2 * MT * 64;          // [hl][b][v][mt][lane] records per (a, cb, k, u) chunk
+    constexpr int NWREG = W_REC / 512;                   // 4 (MT = 4) or 2 (MT = 2)
+    constexpr int IN_STAGE = 2 * IN_REC;
+    __shared__ u32x4 smem[2 * IN_STAGE + 2 * W_REC];
+    u32x4* const in_l = smem;
+    u32x4* const w_l = smem + 2 * IN_STAGE;
+
+    // block -> (input pixel tile, cout block, row parity); XCD = id % 8 keeps every (cb, a) of a pixel tile on one L2
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int per = P.NCB * 2;
+    const int ptile = (slot / per) * 8 + xcd, rem = slot % per, cb = rem >> 1, a = rem & 1;
+    if (ptile >= P.ptiles) return;
+    const int b = blockIdx.y;
+    const int py = ptile / P.PX, px = ptile - py * P.PX;
+    const int y0 = py * TH, x0 = px * TW;              // INPUT coordinates
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kg = lane >> 5;
+    const int wm = wave % WAVES_M, wr = wave / WAVES_M;
+    const size_t HWin = (size_t)P.Hin * P.Win;
+    const float* xb = P.x + (size_t)b * P.Cin * HWin;
+
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const bool has_rec1 = wave_u * 64 + 512 < IN_REC;
+    int soff[2], scg[2];
+    float smask[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int s = tid + 512 * i;
+        if (s >= IN_REC) s = IN_REC - 1;
+        const int cg = s / (ROWS * COLS), p = s - cg * (ROWS * COLS);
+        const int r = p / COLS, c = p - r * COLS;
+        const int gy = y0 + r - 1, gx = x0 + c - 1;
+        const bool inside = gy >= 0 && gy < P.Hin && gx >= 0 && gx < P.Win;
+        scg[i] = cg;
+        soff[i] = inside ? gy * P.Win + gx : 0;
+        smask[i] = inside ? 1.0f : 0.0f;
+    }
+    float rin[2][8];
+    u32x4 rwt[NWREG];
+
+    auto load_input = [&](int k) {
+        {
+            const float* src = xb + (size_t)(k * 16 + scg[0] * 8) * HWin + soff[0];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rin[0][j] = src[(size_t)j * HWin];
+        }
+        if (has_rec1) {
+            const float* src = xb + (size_t)(k * 16 + scg[1] * 8) * HWin + soff[1];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rin[1][j] = src[(size_t)j * HWin];
+        }
+    };
+    auto store_input = [&](int stage) {
+        u32x4* dst = in_l + stage * IN_STAGE;
+        {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = rin[0][j] * smask[0];
+            u32x4 hi, lo;
+            split8(v, hi, lo);
+            dst[tid] = hi;
+            dst[IN_REC + tid] = lo;
+        }
+        if (has_rec1) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = rin[1][j] * smask[1];
+            u32x4 hi, lo;
+            split8(v, hi, lo);
+            if (tid + 512 < IN_REC) {
+                dst[tid + 512] = hi;
+                dst[IN_REC + tid + 512] = lo;
+            }
+        }
+    };
+    const int nph = P.NK * 2;
+    const u32x4* wsrc = P.w + ((size_t)a * P.NCB + cb) * nph * W_REC;
+    auto load_weights = [&](int ph) {
+        const u32x4* src = wsrc + (size_t)ph * W_REC;
+#pragma unroll
+        for (int i = 0; i < NWREG; ++i) rwt[i] = src[tid + 512 * i];
+    };
+    auto store_weights = [&](int stage) {
+        u32x4* dst = w_l + stage * W_REC;
+#pragma unroll
+        for (int i = 0; i < NWREG; ++i) dst[tid + 512 * i] = rwt[i];
+    };
+
+    f32x16 acc[2][2][NROW];   // [b][m][n]
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < NROW; ++n)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[bb][m][n][q] = 0.0f;
+
+    load_input(0);
+    load_weights(0);
+    store_input(0);
+    store_weights(0);
+    __syncthreads();
+
+    for (int ph = 0; ph < nph; ++ph) {
+        const int k = ph >> 1, u = ph & 1;
+        if (u == 0 && k + 1 < P.NK) load_input(k + 1);
+        if (ph + 1 < nph) load_weights(ph + 1);
+
+        const u32x4* wst = w_l + (ph & 1) * W_REC;
+        const u32x4* ist = in_l + (k & 1) * IN_STAGE;
+        const int rbase = kg * ROWS + wr * NROW + a + u;   // halo row of output row n: + n
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {                      // column shift s = b + v
+            bf16x8 bh[NROW], bl[NROW];
+#pragma unroll
+            for (int n = 0; n < NROW; ++n) {
+                const int rec = (rbase + n) * COLS + l31 + s;
+                bh[n] = __builtin_bit_cast(bf16x8, ist[rec]);
+                bl[n] = __builtin_bit_cast(bf16x8, ist[IN_REC + rec]);
+            }
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                const int v = s - bb;
+                if (v < 0 || v > 1) continue;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, wst[(((0 * 2 + bb) * 2 + v) * MT + wm * 2 + m) * 64 + lane]);
+                    const bf16x8 al = __builtin_bit_cast(bf16x8, wst[(((1 * 2 + bb) * 2 + v) * MT + wm * 2 + m) * 64 + lane]);
+#pragma unroll
+                    for (int n = 0; n < NROW; ++n) {
+                        acc[bb][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[n], acc[bb][m][n], 0, 0, 0);   // w_lo * x_hi
+                        acc[bb][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[n], acc[bb][m][n], 0, 0, 0);   // w_hi * x_lo
+                        acc[bb][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[n], acc[bb][m][n], 0, 0, 0);   // w_hi * x_hi
+                    }
+                }
+            }
+        }
+
+        if (ph + 1 < nph) store_weights((ph + 1) & 1);
+        if (u == 1 && k + 1 < P.NK) store_input((k + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: + bias (+ residual); lane owns output px (2X, 2X+1) of row 2Y + a: one float2 per cout
+    const size_t HW = (size_t)P.H * P.W;
+    const int xi = x0 + l31;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int cbase = cb * BM + (wm * 2 + m) * 32 + 4 * kg;
+        float bq[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int co = cbase + (q & 3) + 8 * (q >> 2);
+            bq[q] = P.bias ? P.bias[co < P.Cout ? co : P.Cout - 1] : 0.0f;
+        }
+#pragma unroll
+        for (int n = 0; n < NROW; ++n) {
+            const int yi = y0 + wr * NROW + n;
+            if (yi < P.Hin && xi < P.Win) {
+                const size_t o0 = ((size_t)b * P.Cout) * HW + (size_t)(2 * yi + a) * P.W + 2 * xi;
+                float2 rq[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int co = cbase + (q & 3) + 8 * (q >> 2);
+                    rq[q] = P.res ? *reinterpret_cast<const float2*>(P.res + o0 + (size_t)(co < P.Cout ? co : P.Cout - 1) * HW)
+                                  : make_float2(0.0f, 0.0f);
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int co = cbase + (q & 3) + 8 * (q >> 2);
+                    if (co < P.Cout)
+                        *reinterpret_cast<float2*>(P.y + o0 + (size_t)co * HW) =
+                            make_float2(acc[0][m][n][q] + bq[q] + rq[q].x, acc[1][m][n][q] + bq[q] + rq[q].y);
+                }
+            }
+        }
+    }
+}
+
+// OIHW fp32 -> merged-tap records [a][cb][k][u][hl][b][v][mt][lane] of 8 bf16 (see k_upconv_bf16x3): the taps of a row
+// parity a / tap u are dy in {0} | {1,2} (a = 0) or {0,1} | {2} (a = 1); columns alike.  The merged weight is the fp32 sum
+// in (dy, dx) order.
+__global__ void k_upconv_pack_bf16x3(const float* __restrict__ w, u32x4* __restrict__ out, int Cout, int Cin, int MT, int NCB, int NK) {
+    const size_t n = (size_t)2 * NCB * NK * 2 * 2 * 2 * 2 * MT * 64;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    size_t r = i;
+    const int lane = (int)(r % 64); r /= 64;
+    const int mt = (int)(r % MT); r /= MT;
+    const int v = (int)(r % 2); r /= 2;
+    const int bb = (int)(r % 2); r /= 2;
+    const int hl = (int)(r % 2); r /= 2;
+    const int u = (int)(r % 2); r /= 2;
+    const int k = (int)(r % NK); r /= NK;
+    const int cb = (int)(r % NCB); r /= NCB;
+    const int a = (int)r;
+    const int co = cb * MT * 32 + mt * 32 + (lane & 31);
+    // tap sets: parity p, tap t -> [lo, hi) over the 3x3 index
+    const int dy_lo = a == 0 ? (u == 0 ? 0 : 1) : (u == 0 ? 0 : 2), dy_hi = a == 0 ? (u == 0 ? 1 : 3) : (u == 0 ? 2 : 3);
+    const int dx_lo = bb == 0 ? (v == 0 ? 0 : 1) : (v == 0 ? 0 : 2), dx_hi = bb == 0 ? (v == 0 ? 1 : 3) : (v == 0 ? 2 : 3);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ci = k * 16 + (lane >> 5) * 8 + j;
+        float val = 0.0f;
+        if (co < Cout && ci < Cin)
+            for (int dy = dy_lo; dy < dy_hi; ++dy)
+                for (int dx = dx_lo; dx < dx_hi; ++dx) val += w[(((size_t)co * Cin + ci) * 3 + dy) * 3 + dx];
+        const __bf16 h = (__bf16)val;
+        o[j] = hl == 0 ? h : (__bf16)(val - (float)h);
+    }
+    out[i] = __builtin_bit_cast(u32x4, o);
+}
+
 inline int round_up_i(int v, int m) { return (v + m - 1) / m * m; }
 
 }  // namespace
@@ -271,15 +500,26 @@ namespace mdt {
 bool conv_bf16x3_eligible(int cout, int cin, int ksize) { return ksize == 3 && cin % 16 == 0 && cout >= 32; }
 static int conv_bf16x3_mt(int cout) { return cout > 64 ? 4 : 2; }
 
-size_t conv_bf16x3_packed_floats(int cout, int cin) {   // size of the record array in floats (4 per 16-byte record)
+// record image = [ direct 3x3 records (9 taps) | sub-pixel upsample records (4 parities x 4 merged taps) ]
+static size_t direct_records(int cout, int cin) {
     const int MT = conv_bf16x3_mt(cout), NCB = round_up_i(cout, MT * 32) / (MT * 32), NK = cin / 16;
-    return (size_t)NCB * NK * 3 * 2 * 3 * MT * 64 * 4;
+    return (size_t)NCB * NK * 3 * 2 * 3 * MT * 64;
+}
+static size_t upconv_records(int cout, int cin) {
+    const int MT = conv_bf16x3_mt(cout), NCB = round_up_i(cout, MT * 32) / (MT * 32), NK = cin / 16;
+    return (size_t)2 * NCB * NK * 2 * 2 * 2 * 2 * MT * 64;
+}
+size_t conv_bf16x3_packed_floats(int cout, int cin) {   // size of the record array in floats (4 per 16-byte record)
+    return (direct_records(cout, cin) + upconv_records(cout, cin)) * 4;
 }
 
 int conv_bf16x3_pack(const float* d_w_oihw, void* d_out, int cout, int cin, hipStream_t s) {
     const int MT = conv_bf16x3_mt(cout), NCB = round_up_i(cout, MT * 32) / (MT * 32), NK = cin / 16;
     const size_t n = (size_t)NCB * NK * 3 * 2 * 3 * MT * 64;
     hipLaunchKernelGGL(k_conv_pack_bf16x3, dim3(cdiv((long long)n, 256)), dim3(256), 0, s, d_w_oihw, (u32x4*)d_out, cout, cin, MT, NCB, NK);
+    MDT_LAUNCH_CHECK();
+    const size_t nu = upconv_records(cout, cin);
+    hipLaunchKernelGGL(k_upconv_pack_bf16x3, dim3(cdiv((long long)nu, 256)), dim3(256), 0, s, d_w_oihw, (u32x4*)d_out + n, cout, cin, MT, NCB, NK);
     MDT_LAUNCH_CHECK();
     return MDTILE_OK;
 }
@@ -291,13 +531,31 @@ int conv_bf16x3_launch(const float* d_x, const void* d_w_rec, const float* d_bia
     P.B = B; P.Cin = cin; P.Cout = cout; P.H = H; P.W = W;
     P.Hin = up ? H / 2 : H; P.Win = up ? W / 2 : W; P.up = up;
     const int MT = conv_bf16x3_mt(cout);
+    // fused nearest-2x: sub-pixel form (four 2x2 convs on the input grid) unless MDTILE_UPCONV=direct asks for the 9-tap walk
+    static const bool up_direct = [] { const char* e = getenv("MDTILE_UPCONV"); return e && strcmp(e, "direct") == 0; }();
+    if (up && !up_direct) {
+        P.w = (const u32x4*)d_w_rec + direct_records(cout, cin);
+        P.PX = (P.Win + TW - 1) / TW;
+        P.ptiles = P.PX * ((P.Hin + TH - 1) / TH);
+        P.NCB = round_up_i(cout, MT * 32) / (MT * 32);
+        P.NK = cin / 16;
+        dim3 grid(((P.ptiles + 7) / 8) * 8 * P.NCB * 2, B), block(512);
+        if (MT == 4) hipLaunchKernelGGL(k_upconv_bf16x3<4>, grid, block, 0, s, P);
+        else hipLaunchKernelGGL(k_upconv_bf16x3<2>, grid, block, 0, s, P);
+        MDT_LAUNCH_CHECK();
+        return MDTILE_OK;
+    }
+    // pixel rows per block: 8 (default) or 16 (MDTILE_CONV_TH=16: 2x the MFMAs per barrier and per weight stage, MT = 4 only)
+    static const int th_env = [] { const char* e = getenv("MDTILE_CONV_TH"); return e ? atoi(e) : 0; }();
+    const int th = (MT == 4 && th_env == 16 && H >= 16) ? 16 : TH;
     P.PX = (W + TW - 1) / TW;
-    P.ptiles = P.PX * ((H + TH - 1) / TH);
+    P.ptiles = P.PX * ((H + th - 1) / th);
     P.NCB = round_up_i(cout, MT * 32) / (MT * 32);
     P.NK = cin / 16;
     dim3 grid(((P.ptiles + 7) / 8) * 8 * P.NCB, B), block(512);
-    if (MT == 4) hipLaunchKernelGGL(k_conv3x3_bf16x3<4>, grid, block, 0, s, P);
-    else hipLaunchKernelGGL(k_conv3x3_bf16x3<2>, grid, block, 0, s, P);
+    if (MT == 4 && th == 16) hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 16>), grid, block, 0, s, P);
+    else if (MT == 4) hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 8>), grid, block, 0, s, P);
+    else hipLaunchKernelGGL((k_conv3x3_bf16x3<2, 8>), grid, block, 0, s, P);
     MDT_LAUNCH_CHECK();
     return MDTILE_OK;
 }

@@ -20,6 +20,11 @@ SHAPES = [  # cin, cout, k, H, W, upsample   (one 278x278-latent decoder tile of
     (256, 128, 3, 2224, 2224, False),
     (128, 128, 3, 2224, 2224, False),
 ]
+# usage: conv_probe.py [--no-exact] [--shapes 0,2,5]     (env MDTILE_CONV_TH=16 / MDTILE_UPCONV=direct select kernel variants)
+NO_EXACT = "--no-exact" in sys.argv
+if "--shapes" in sys.argv:
+    SHAPES = [SHAPES[int(i)] for i in sys.argv[sys.argv.index("--shapes") + 1].split(",")]
+print(f"variant: MDTILE_CONV_TH={os.environ.get('MDTILE_CONV_TH', '8')} MDTILE_UPCONV={os.environ.get('MDTILE_UPCONV', 'subpixel')}", flush=True)
 torch.manual_seed(0)
 for cin, cout, k, H, W, up in SHAPES:
     conv = torch.nn.Conv2d(cin, cout, k, 1, k // 2).to(dev)
@@ -30,7 +35,7 @@ for cin, cout, k, H, W, up in SHAPES:
     flops = 2.0 * H * W * cout * cin * k * k
     outs = {}
     line = f"{cin:4d}->{cout:4d} k{k} {H}x{W}{' up' if up else '   '}: "
-    for exact in (False, True):
+    for exact in ((False,) if NO_EXACT else (False, True)):
         y = pc(x, residual=res, upsample2x=up, exact=exact)
         torch.cuda.synchronize()
         n = 3 if exact else 6
@@ -43,6 +48,6 @@ for cin, cout, k, H, W, up in SHAPES:
         ms = s.elapsed_time(e) / n
         outs[exact] = y
         line += f"{'f32   ' if exact else 'bf16x3'} {ms:8.3f} ms {flops / ms * 1e-9:7.1f} TF   "
-    err = ((outs[False] - outs[True]).abs().max() / outs[True].abs().max()).item()
+    err = float("nan") if NO_EXACT else ((outs[False] - outs[True]).abs().max() / outs[True].abs().max()).item()
     print(line + f"max dev {err:.2e}", flush=True)
     del x, res, outs, y

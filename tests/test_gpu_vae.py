@@ -76,6 +76,9 @@ CONV_CASES = [  # B, cin, cout, k, H, W, upsample, residual, token_major
     (1, 256, 256, 3, 70, 100, False, True, False),   # many pixel tiles x 2 cout blocks (block -> XCD mapping)
     (2, 256, 128, 3, 40, 36, True, True, False),     # upsample + residual + batch, cout block of 128 from 256 cin
     (1, 48, 160, 3, 11, 33, False, False, False),    # cin = 3 K-steps, cout padded 160 -> 256
+    (1, 512, 512, 3, 74, 100, True, False, False),   # sub-pixel upsample conv: ragged input tiles (37 x 50), 4 cout blocks
+    (1, 64, 64, 3, 18, 66, True, True, False),       # sub-pixel upsample conv, 64-cout block variant + residual
+    (1, 256, 256, 3, 50, 70, False, False, False),   # 16-row blocks when MDTILE_CONV_TH=16
 ]
 
 
