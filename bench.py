@@ -224,14 +224,19 @@ def main():
                 prof.wrap("blend", blend_bytes, lambda: E.blend(plan, method, [tile_out], N, C, out=blend_out, packed=True, **kw))
         if hook is not None:
             orig_call = E.PackedConv.__call__
+            subpixel = os.environ.get("MDTILE_UPCONV", "") != "direct" and os.environ.get("MDTILE_CONV_MODE", "") != "f32"
 
-            def timed_call(self, x, residual=None, upsample2x=False, token_major=False):
+            def timed_call(self, x, residual=None, upsample2x=False, token_major=False, exact=False, pre_gn=None):
                 B, cin, H, W = x.shape
                 if upsample2x:
                     H, W = 2 * H, 2 * W
                 flops = 2.0 * B * H * W * self.cout * cin * self.ksize * self.ksize
                 tag = f"conv{self.ksize}x{self.ksize}_{'wide' if ((self.cout + 31) // 32 * 32) > 64 else 'narrow'}"
-                return prof.wrap(tag, flops, lambda: orig_call(self, x, residual, upsample2x, token_major))
+                if upsample2x and self.ksize == 3 and subpixel:
+                    # sub-pixel form of nearest-2x + 3x3 conv: four 2x2 convs -> 4/9 of the MACs are EXECUTED; count those
+                    flops *= 4.0 / 9.0
+                    tag = "upconv_subpixel"
+                return prof.wrap(tag, flops, lambda: orig_call(self, x, residual, upsample2x, token_major, exact, pre_gn))
 
             orig_attn = E.vae_attn
 
@@ -255,14 +260,14 @@ def main():
             roofline_blend = {"kernel": "k_blend", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "launches": n,
                               "avg_us": round(secs / n * 1e6, 2), "bytes_per_launch": int(work / n)}
-        conv_tags = {k: v for k, v in agg.items() if k.startswith("conv") or k == "attn"}
+        conv_tags = {k: v for k, v in agg.items() if k.startswith("conv") or k.startswith("upconv") or k == "attn"}
         if conv_tags:
             dom = max(conv_tags, key=lambda k_: conv_tags[k_][2])
             n, work, secs = conv_tags[dom]
             ach = work / secs / 1e12
             # which matrix-core path the dominant kernel ran on: 3x3 convs with cin % 16 == 0 and attention use the
             # split-bf16 kernels unless MDTILE_CONV_MODE=f32 / the exact flag is set; 1x1 convs and narrow convs are fp32 MFMA
-            bf16x3 = os.environ.get("MDTILE_CONV_MODE", "") != "f32" and dom in ("conv3x3_wide", "attn")
+            bf16x3 = os.environ.get("MDTILE_CONV_MODE", "") != "f32" and dom in ("conv3x3_wide", "upconv_subpixel", "attn")
             peak = MFMA_BF16X3_PEAK_TFLOPS if bf16x3 else MFMA_F32_PEAK_TFLOPS
             roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                         "frac": round(ach / peak, 4), "traffic": None, "launches": n,

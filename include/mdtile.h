@@ -196,6 +196,18 @@ int mdtile_conv_pack(const float* d_w_oihw, float* d_w_packed, int cout, int cin
 int mdtile_conv2d(const float* d_x, const float* d_w_packed, const float* d_bias, const float* d_residual, float* d_y,
                   int B, int cin, int cout, int H, int W, int ksize, int flags, int out_layout, mdtile_stream_t stream);
 
+/* Fused pre-activation: the fixed-statistics GroupNorm + SiLU that precedes conv1 / conv2 of every ResnetBlock
+ * (custom_group_norm + inplace_nonlinearity, tilevae.py:218-245, 102-104; queue order pre_norm, silu, conv1 ... :115-137)
+ * is applied while the conv stages its input, so the normalised activation never makes a round trip through HBM.
+ *   mdtile_gn_coeffs           : d_coef[B][2][C] = { a = gamma / sqrt(var + eps), s = beta - mean * a } (same constants as mdtile_gn_apply)
+ *   mdtile_conv2d_gn           : y = conv(silu(a * x + s)) + bias (+ residual); 3x3, stride 1, split-bf16 kernel only
+ *   mdtile_conv2d_gn_supported : 1 when such a kernel exists for the shape / flags (else use mdtile_gn_apply + mdtile_conv2d) */
+int mdtile_gn_coeffs(const float* d_mean, const float* d_var, const float* d_gamma, const float* d_beta, int B, int C, int groups,
+                     float eps, float* d_coef, mdtile_stream_t stream);
+int mdtile_conv2d_gn_supported(int cout, int cin, int ksize, int flags, int out_layout);
+int mdtile_conv2d_gn(const float* d_x, const float* d_coef, const float* d_w_packed, const float* d_bias, const float* d_residual,
+                     float* d_y, int B, int cin, int cout, int H, int W, int ksize, int flags, mdtile_stream_t stream);
+
 /* attn_forward body between the 1x1 convs (tile_utils/attn.py:55-70): single head,
  * out[b,c,i] = sum_j v[b,c,j] * softmax_j(scale * sum_c' q[b,c',i] k[b,c',j]).
  * q,k: [B,C,T] channel-major;  v: [B,T,C] token-major (conv out_layout 1);  out: [B,C,T].  C = 128, 256 or 512.

@@ -100,7 +100,8 @@ __global__ __launch_bounds__(256) void k_attn_prep_v(const float* __restrict__ s
 
 template <int C>
 __global__ __launch_bounds__(512) void k_attn_bf16x3(const u32x4* __restrict__ Qr, const u32x4* __restrict__ Kr, const u32x4* __restrict__ Vr,
-                                                     float* __restrict__ out, int T, int T128, float scale) {
+                                                     float* __restrict__ out, int T, int T128, float scale, int nsplit,
+                                                     float* __restrict__ part, float* __restrict__ pstat) {
     constexpr int NKS = C / 16, NMT = C / 32, NSS = NKS / 2;        // channel k-steps, 32-channel output tiles, score slabs
     constexpr int WAVES_M = NMT < 8 ? NMT : 8, WAVES_N = 8 / WAVES_M, MT_W = NMT / WAVES_M, NT_W = 4 / WAVES_N;
     constexpr int PV_REC = NMT * 2 * 64;                            // records of one V slab (16 keys)
@@ -159,9 +160,14 @@ __global__ __launch_bounds__(512) void k_attn_bf16x3(const u32x4* __restrict__ Q
             for (int r = 0; r < 16; ++r) acc_o[m][n][r] = 0.0f;
     float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.0f, 0.0f};   // for queries (2*qh + j)*32 + l31
 
+    // key-range split (blockIdx.z): with 1 block per CU a 604-block launch leaves the last of its 3 rounds 2/3 empty; splitting
+    // every query block's keys nsplit ways evens the rounds out.  Each part keeps its own running (max, sum) and an
+    // un-normalised output; k_attn_combine merges them.
+    const int split = blockIdx.z;
+    const int kb_lo = (int)((long long)nkb * split / nsplit), kb_hi = (int)((long long)nkb * (split + 1) / nsplit);
     int buf = 0;
-    issue_S(0, 0);
-    for (int kb = 0; kb < nkb; ++kb) {
+    issue_S(kb_lo, 0);
+    for (int kb = kb_lo; kb < kb_hi; ++kb) {
         // ------------------------------------------------ scores: St tiles (kt_w, 2*qh + j), all channels
         f32x16 st[2];
 #pragma unroll
@@ -263,7 +269,7 @@ __global__ __launch_bounds__(512) void k_attn_bf16x3(const u32x4* __restrict__ Q
             write_V(buf);
             __syncthreads();
             if (p + 1 < 8) issue_V(kb, p + 1);
-            else if (kb + 1 < nkb) issue_S(kb + 1, 0);
+            else if (kb + 1 < kb_hi) issue_S(kb + 1, 0);
             const u32x4* sl = slab + buf * SLAB_REC;
             bf16x8 vh[MT_W], vl[MT_W];
 #pragma unroll
@@ -291,9 +297,34 @@ __global__ __launch_bounds__(512) void k_attn_bf16x3(const u32x4* __restrict__ Q
     __syncthreads();
     if (kt_w == 0 && kg == 0) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) ssum[(2 * qh + j) * 32 + l31] = l_run[j];
+        for (int j = 0; j < 2; ++j) {
+            const int ql = (2 * qh + j) * 32 + l31;
+            ssum[ql] = l_run[j];
+            if (nsplit > 1) {   // (max, sum) of this part, per query: pstat[split][b][2][T128]
+                float* ps = pstat + ((size_t)(split * gridDim.y + b) * 2) * T128 + qb * BQ + ql;
+                ps[0] = m_run[j];
+                ps[T128] = l_run[j];
+            }
+        }
     }
     __syncthreads();
+    if (nsplit > 1) {
+        float* ob = part + (size_t)(split * gridDim.y + b) * C * T;   // un-normalised part, same [C][T] layout as out
+#pragma unroll
+        for (int n = 0; n < NT_W; ++n) {
+            const int q = qb * BQ + (wn * NT_W + n) * 32 + l31;
+            if (q < T) {
+#pragma unroll
+                for (int m = 0; m < MT_W; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int c = (wm * MT_W + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                        ob[(size_t)c * T + q] = acc_o[m][n][r];
+                    }
+            }
+        }
+        return;
+    }
     float* ob = out + (size_t)b * C * T;
 #pragma unroll
     for (int n = 0; n < NT_W; ++n) {
@@ -312,16 +343,70 @@ __global__ __launch_bounds__(512) void k_attn_bf16x3(const u32x4* __restrict__ Q
     }
 }
 
+// merge the key-range parts of a query: out = sum_s O_s e^(m_s - m) / sum_s l_s e^(m_s - m), m = max_s m_s
+__global__ __launch_bounds__(256) void k_attn_combine(const float* __restrict__ part, const float* __restrict__ pstat, float* __restrict__ out,
+                                                      int B, int C, int T, int T128, int nsplit) {
+    const int q = blockIdx.x * 256 + threadIdx.x, b = blockIdx.z;
+    if (q >= T) return;
+    float w[4], m = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) m = fmaxf(m, pstat[((size_t)(s * B + b) * 2) * T128 + q]);
+    float den = 0.0f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float* ps = pstat + ((size_t)(s * B + b) * 2) * T128 + q;
+        w[s] = expf(ps[0] - m);
+        den += ps[T128] * w[s];
+    }
+    const float inv = 1.0f / den;
+    for (int c = blockIdx.y; c < C; c += gridDim.y) {
+        float o = 0.0f;
+        for (int s = 0; s < nsplit; ++s) o += part[((size_t)(s * B + b) * C + c) * T + q] * w[s];
+        out[((size_t)b * C + c) * T + q] = o * inv;
+    }
+}
+
 }  // namespace
 
 namespace mdt {
 
 bool attn_bf16x3_eligible(int C) { return C == 128 || C == 256 || C == 512; }
 
-// workspace: Qrec, Krec, Vrec, each B * T128 * C * 4 bytes (hi + lo bf16 per element)
+// Key-range split factor: 1 block per CU (133 KB LDS), so the launch runs in ceil(blocks / CUs) rounds; pick the smallest
+// nsplit <= 4 whose round occupancy is within 3 % of the best.  MDTILE_ATTN_SPLIT=n forces it.
+static int attn_num_cus() {
+    static const int n = [] {
+        int dev = 0, cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount;
+        return cus;
+    }();
+    return n;
+}
+static int attn_nsplit(int B, int T) {
+    static const int forced = [] { const char* e = getenv("MDTILE_ATTN_SPLIT"); return e ? atoi(e) : 0; }();
+    const int nkb = (T + 127) / 128;
+    if (forced >= 1 && forced <= 4) return forced <= nkb ? forced : 1;
+    const long long blocks = (long long)B * nkb;
+    const int cus = attn_num_cus();
+    double eff[5], best = 0.0;
+    for (int s = 1; s <= 4; ++s) {
+        const long long rounds = (blocks * s + cus - 1) / cus;
+        eff[s] = s <= nkb ? (double)(blocks * s) / (double)(rounds * cus) : 0.0;
+        if (eff[s] > best) best = eff[s];
+    }
+    for (int s = 1; s <= 4; ++s)
+        if (eff[s] >= best - 0.03) return s;
+    return 1;
+}
+
+// workspace: Qrec, Krec, Vrec, each B * T128 * C * 4 bytes (hi + lo bf16 per element) [+ nsplit un-normalised parts
+// B*C*T fp32 and their (max, sum) rows 2*B*T128 fp32 when the key range is split]
 size_t attn_bf16x3_ws_bytes(int B, int C, int T) {
     const size_t T128 = ((size_t)T + 127) / 128 * 128;
-    return 3 * (size_t)B * T128 * C * 4;
+    const int ns = attn_nsplit(B, T);
+    size_t bytes = 3 * (size_t)B * T128 * C * 4;
+    if (ns > 1) bytes += (size_t)ns * ((size_t)B * C * T + 2 * (size_t)B * T128) * 4;
+    return bytes;
 }
 
 int attn_bf16x3_launch(const float* d_q, const float* d_k, const float* d_v_tok, float* d_out, int B, int C, int T, float scale, void* d_ws,
@@ -331,6 +416,9 @@ int attn_bf16x3_launch(const float* d_q, const float* d_k, const float* d_v_tok,
     u32x4* Qr = (u32x4*)d_ws;
     u32x4* Kr = Qr + per;
     u32x4* Vr = Kr + per;
+    const int ns = attn_nsplit(B, T);
+    float* part = (float*)(Vr + per);
+    float* pstat = part + (size_t)ns * B * C * T;
     const int tiles = T128 / 32, groups = T128 / 16;
     {
         const size_t n = (size_t)tiles * (C / 16) * 64;
@@ -344,11 +432,16 @@ int attn_bf16x3_launch(const float* d_q, const float* d_k, const float* d_v_tok,
         hipLaunchKernelGGL(k_attn_prep_v, grid, dim3(256), 0, s, d_v_tok, Vr, C, T, groups);
     }
     MDT_LAUNCH_CHECK();
-    dim3 grid(T128 / BQ, B), block(512);
-    if (C == 512) hipLaunchKernelGGL(k_attn_bf16x3<512>, grid, block, 0, s, Qr, Kr, Vr, d_out, T, T128, scale);
-    else if (C == 256) hipLaunchKernelGGL(k_attn_bf16x3<256>, grid, block, 0, s, Qr, Kr, Vr, d_out, T, T128, scale);
-    else hipLaunchKernelGGL(k_attn_bf16x3<128>, grid, block, 0, s, Qr, Kr, Vr, d_out, T, T128, scale);
+    dim3 grid(T128 / BQ, B, ns), block(512);
+    if (C == 512) hipLaunchKernelGGL(k_attn_bf16x3<512>, grid, block, 0, s, Qr, Kr, Vr, d_out, T, T128, scale, ns, part, pstat);
+    else if (C == 256) hipLaunchKernelGGL(k_attn_bf16x3<256>, grid, block, 0, s, Qr, Kr, Vr, d_out, T, T128, scale, ns, part, pstat);
+    else hipLaunchKernelGGL(k_attn_bf16x3<128>, grid, block, 0, s, Qr, Kr, Vr, d_out, T, T128, scale, ns, part, pstat);
     MDT_LAUNCH_CHECK();
+    if (ns > 1) {
+        dim3 cgrid(cdiv(T, 256), C < 64 ? C : 64, B);
+        hipLaunchKernelGGL(k_attn_combine, cgrid, dim3(256), 0, s, part, pstat, d_out, B, C, T, T128, ns);
+        MDT_LAUNCH_CHECK();
+    }
     return MDTILE_OK;
 }
 

@@ -214,8 +214,9 @@ namespace mdt {
 bool conv_bf16x3_eligible(int cout, int cin, int ksize);
 size_t conv_bf16x3_packed_floats(int cout, int cin);
 int conv_bf16x3_pack(const float* d_w_oihw, void* d_out, int cout, int cin, hipStream_t s);
+bool conv_bf16x3_gn_supported(int cout, int cin, int ksize, int up);
 int conv_bf16x3_launch(const float* d_x, const void* d_w_rec, const float* d_bias, const float* d_res, float* d_y, int B, int cin,
-                       int cout, int H, int W, int up, hipStream_t s);
+                       int cout, int H, int W, int up, const float* d_coef, hipStream_t s);
 }  // namespace mdt
 
 // packed buffer = [ fp32 image (tap, cin, coutP) | split-bf16 record image (only for shapes the bf16x3 kernel takes) ]
@@ -254,7 +255,7 @@ extern "C" int mdtile_conv2d(const float* d_x, const float* d_w_packed, const fl
     // split-bf16 matrix-core path (16/3 x the fp32-MFMA rate, ~1e-5 relative): default for the 3x3 convs it covers
     static const bool force_f32 = [] { const char* e = getenv("MDTILE_CONV_MODE"); return e && strcmp(e, "f32") == 0; }();
     if (!force_f32 && !(flags & MDTILE_CONV_EXACT_F32) && out_layout == 0 && conv_bf16x3_eligible(cout, cin, ksize))
-        return conv_bf16x3_launch(d_x, d_w_packed + f32_packed_floats(cout, cin, ksize), d_bias, d_residual, d_y, B, cin, cout, H, W, up, s);
+        return conv_bf16x3_launch(d_x, d_w_packed + f32_packed_floats(cout, cin, ksize), d_bias, d_residual, d_y, B, cin, cout, H, W, up, nullptr, s);
     const bool wide = P.CoutP > 64;
     if (ksize == 3) {
         if (wide) return launch_conv<3, 8, 2, 2, 4, 2>(P, out_layout, s);
@@ -262,4 +263,25 @@ extern "C" int mdtile_conv2d(const float* d_x, const float* d_w_packed, const fl
     }
     if (wide) return launch_conv<1, 16, 2, 2, 4, 2>(P, out_layout, s);
     return launch_conv<1, 16, 4, 1, 2, 1>(P, out_layout, s);
+}
+
+static bool conv_force_f32() {
+    static const bool v = [] { const char* e = getenv("MDTILE_CONV_MODE"); return e && strcmp(e, "f32") == 0; }();
+    return v;
+}
+
+extern "C" int mdtile_conv2d_gn_supported(int cout, int cin, int ksize, int flags, int out_layout) {
+    if (conv_force_f32() || (flags & MDTILE_CONV_EXACT_F32) || out_layout != 0) return 0;
+    return conv_bf16x3_gn_supported(cout, cin, ksize, (flags & MDTILE_CONV_UPSAMPLE2X) ? 1 : 0) ? 1 : 0;
+}
+
+extern "C" int mdtile_conv2d_gn(const float* d_x, const float* d_coef, const float* d_w_packed, const float* d_bias, const float* d_residual,
+                                float* d_y, int B, int cin, int cout, int H, int W, int ksize, int flags, mdtile_stream_t stream) {
+    MDT_CHECK_ARG(d_x && d_coef && d_w_packed && d_y, "mdtile_conv2d_gn: null argument");
+    MDT_CHECK_ARG(B > 0 && B <= 65535 && cin > 0 && cout > 0 && H > 0 && W > 0, "mdtile_conv2d_gn: bad shape B=%d cin=%d cout=%d H=%d W=%d", B, cin, cout, H, W);
+    MDT_CHECK_ARG(mdtile_conv2d_gn_supported(cout, cin, ksize, flags, 0),
+                  "mdtile_conv2d_gn: no fused pre-activation kernel for cout=%d cin=%d ksize=%d flags=%d (use mdtile_gn_apply + mdtile_conv2d)", cout, cin, ksize, flags);
+    MDT_CHECK_ARG((size_t)H * W < (1u << 24), "mdtile_conv2d_gn: input plane too large for the staging map");
+    return conv_bf16x3_launch(d_x, d_w_packed + f32_packed_floats(cout, cin, ksize), d_bias, d_residual, d_y, B, cin, cout, H, W, 0, d_coef,
+                              as_stream(stream));
 }

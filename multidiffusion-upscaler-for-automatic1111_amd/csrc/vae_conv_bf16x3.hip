@@ -40,7 +40,10 @@ struct ConvBParams {
     int B, Cin, Cout, H, W;   // H, W: OUTPUT spatial size
     int Hin, Win, up;         // input spatial size; up = 1 for fused nearest-2x
     int ptiles, PX, NCB, NK;  // pixel tiles, tiles per row, cout blocks, 16-channel K-steps
+    const float* coef;        // fused pre-activation (GNS kernels): [B][2][Cin] = per-channel scale a, shift s; x' = silu(a x + s)
 };
+
+constexpr int MAX_GN_CIN = 512;   // the fused pre-activation keeps a[Cin], s[Cin] in LDS
 
 constexpr int TH = 8, TW = 32, ROWS = TH + 2, COLS = TW + 2;
 constexpr int IN_REC = 2 * ROWS * COLS;                 // 680 records (16 B) per hl per stage
@@ -56,7 +59,11 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo
     lo = __builtin_bit_cast(u32x4, l);
 }
 
-template <int MT, int TH_>  // MT: 32-cout tiles per block, 4 (BM = 128) or 2 (BM = 64); TH_: pixel rows per block, 8 or 16
+// GNS = true: the fixed-statistics GroupNorm + SiLU that precedes conv1 / conv2 in every resblock (custom_group_norm +
+// inplace_nonlinearity, scripts/tilevae.py:218-245, 102-104) is applied to the input while it is staged:
+// x' = silu(fma(x, a[c], s[c])) with a = gamma * rstd, s = beta - mean * a (mdtile_gn_coeffs) -- the normalised activation is
+// never written to HBM (1R + 1W of every pre-conv activation saved).  Zero padding applies to x' (mask after the transform).
+template <int MT, int TH_, bool GNS>  // MT: 32-cout tiles per block, 4 (BM = 128) or 2 (BM = 64); TH_: pixel rows per block, 8 or 16
 __global__ __launch_bounds__(512) void k_conv3x3_bf16x3(const ConvBParams P) {
     constexpr int BM = MT * 32;
     constexpr int WAVES_M = MT / 2, WAVES_R = 8 / WAVES_M, NROW = TH_ / WAVES_R;
@@ -67,6 +74,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16x3(const ConvBParams P) {
     // LDS (16-byte records): input [2 stages][hl][IN_REC_], weights [2 stages][W_REC]
     constexpr int IN_STAGE = 2 * IN_REC_;
     __shared__ u32x4 smem[2 * IN_STAGE + 2 * W_REC];
+    __shared__ float4 coef_l[GNS ? 2 * MAX_GN_CIN / 4 : 1];   // a[0..Cin) at 0, s[0..Cin) at MAX_GN_CIN
     u32x4* const in_l = smem;
     u32x4* const w_l = smem + 2 * IN_STAGE;
 
@@ -77,6 +85,15 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16x3(const ConvBParams P) {
     const int b = blockIdx.y;
     const int py = ptile / P.PX, px = ptile - py * P.PX;
     const int y0 = py * TH_, x0 = px * TW;
+    if (GNS) {
+        float* cl = reinterpret_cast<float*>(coef_l);
+        const float* cg = P.coef + (size_t)b * 2 * P.Cin;
+        for (int c = threadIdx.x; c < P.Cin; c += 512) {
+            cl[c] = cg[c];
+            cl[MAX_GN_CIN + c] = cg[P.Cin + c];
+        }
+        __syncthreads();
+    }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kg = lane >> 5;
     const int wm = wave % WAVES_M, wr = wave / WAVES_M;
@@ -114,14 +131,27 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16x3(const ConvBParams P) {
             }
         }
     };
-    auto store_input = [&](int stage) {
+    auto store_input = [&](int stage, int k) {   // k: the K-step held in rin (channels 16k ..)
         u32x4* dst = in_l + stage * IN_STAGE;
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
             if (wave_u * 64 + 512 * i < IN_REC_) {
                 float v[8];
+                if (GNS) {
+                    const int c4 = (k * 16 + scg[i] * 8) >> 2;
+                    const float4 a0 = coef_l[c4], a1 = coef_l[c4 + 1], s0 = coef_l[MAX_GN_CIN / 4 + c4], s1 = coef_l[MAX_GN_CIN / 4 + c4 + 1];
+                    const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                    const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = rin[i][j] * smask[i];
+                    for (int j = 0; j < 8; ++j) {
+                        const float t = fmaf(rin[i][j], av[j], sv[j]);
+                        // silu(t) = t / (1 + e^-t): v_exp_f32 + v_rcp_f32 (<= ~2 ulp; the operands are rounded to 16 bits next)
+                        v[j] = smask[i] != 0.0f ? t * __builtin_amdgcn_rcpf(1.0f + __expf(-t)) : 0.0f;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = rin[i][j] * smask[i];
+                }
                 u32x4 hi, lo;
                 split8(v, hi, lo);
                 if (tid + 512 * i < IN_REC_) {
@@ -156,7 +186,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16x3(const ConvBParams P) {
     const int nph = P.NK * 3;
     load_input(0);
     load_weights(0);
-    store_input(0);
+    store_input(0, 0);
     store_weights(0);
     __syncthreads();
 
@@ -190,7 +220,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16x3(const ConvBParams P) {
         }
 
         if (ph + 1 < nph) store_weights((ph + 1) & 1);
-        if (dy == 2 && k + 1 < P.NK) store_input((k + 1) & 1);
+        if (dy == 2 && k + 1 < P.NK) store_input((k + 1) & 1, k + 1);
         __syncthreads();
     }
 
@@ -524,9 +554,14 @@ int conv_bf16x3_pack(const float* d_w_oihw, void* d_out, int cout, int cin, hipS
     return MDTILE_OK;
 }
 
+bool conv_bf16x3_gn_supported(int cout, int cin, int ksize, int up) {
+    return conv_bf16x3_eligible(cout, cin, ksize) && !up && cin <= MAX_GN_CIN;
+}
+
 int conv_bf16x3_launch(const float* d_x, const void* d_w_rec, const float* d_bias, const float* d_res, float* d_y, int B, int cin,
-                       int cout, int H, int W, int up, hipStream_t s) {
+                       int cout, int H, int W, int up, const float* d_coef, hipStream_t s) {
     ConvBParams P;
+    P.coef = d_coef;
     P.x = d_x; P.w = (const u32x4*)d_w_rec; P.bias = d_bias; P.res = d_res; P.y = d_y;
     P.B = B; P.Cin = cin; P.Cout = cout; P.H = H; P.W = W;
     P.Hin = up ? H / 2 : H; P.Win = up ? W / 2 : W; P.up = up;
@@ -553,9 +588,15 @@ int conv_bf16x3_launch(const float* d_x, const void* d_w_rec, const float* d_bia
     P.NCB = round_up_i(cout, MT * 32) / (MT * 32);
     P.NK = cin / 16;
     dim3 grid(((P.ptiles + 7) / 8) * 8 * P.NCB, B), block(512);
-    if (MT == 4 && th == 16) hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 16>), grid, block, 0, s, P);
-    else if (MT == 4) hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 8>), grid, block, 0, s, P);
-    else hipLaunchKernelGGL((k_conv3x3_bf16x3<2, 8>), grid, block, 0, s, P);
+    if (d_coef) {
+        if (MT == 4 && th == 16) hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 16, true>), grid, block, 0, s, P);
+        else if (MT == 4) hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 8, true>), grid, block, 0, s, P);
+        else hipLaunchKernelGGL((k_conv3x3_bf16x3<2, 8, true>), grid, block, 0, s, P);
+    } else {
+        if (MT == 4 && th == 16) hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 16, false>), grid, block, 0, s, P);
+        else if (MT == 4) hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 8, false>), grid, block, 0, s, P);
+        else hipLaunchKernelGGL((k_conv3x3_bf16x3<2, 8, false>), grid, block, 0, s, P);
+    }
     MDT_LAUNCH_CHECK();
     return MDTILE_OK;
 }

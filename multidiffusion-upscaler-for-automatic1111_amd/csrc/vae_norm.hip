@@ -263,6 +263,31 @@ static int eltwise_grid(size_t n) {
     return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
 }
 
+// Per-(sample, channel) affine of a fixed-statistics GroupNorm -- exactly the two constants k_gn_apply forms per plane:
+// a = gamma / sqrt(var + eps), s = fma(-mean, a, beta).  Layout [B][2][C] (a row, then s row), consumed by mdtile_conv2d_gn.
+__global__ void k_gn_coeffs(const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ gamma,
+                            const float* __restrict__ beta, int B, int C, int cpg, int groups, float eps, float* __restrict__ coef) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i - b * C;
+    const int g = b * groups + c / cpg;
+    const float rstd = 1.0f / sqrtf(var[g] + eps);
+    const float ga = gamma ? gamma[c] : 1.0f, be = beta ? beta[c] : 0.0f;
+    const float a = rstd * ga;
+    coef[((size_t)b * 2 + 0) * C + c] = a;
+    coef[((size_t)b * 2 + 1) * C + c] = fmaf(-mean[g], a, be);
+}
+
+extern "C" int mdtile_gn_coeffs(const float* d_mean, const float* d_var, const float* d_gamma, const float* d_beta, int B, int C, int groups,
+                                float eps, float* d_coef, mdtile_stream_t stream) {
+    MDT_CHECK_ARG(d_mean && d_var && d_coef, "mdtile_gn_coeffs: null argument");
+    MDT_CHECK_ARG(B > 0 && C > 0 && groups > 0 && C % groups == 0, "mdtile_gn_coeffs: C=%d not divisible by groups=%d", C, groups);
+    hipLaunchKernelGGL(k_gn_coeffs, dim3(cdiv((long long)B * C, 256)), dim3(256), 0, as_stream(stream), d_mean, d_var, d_gamma, d_beta, B, C,
+                       C / groups, groups, eps, d_coef);
+    MDT_LAUNCH_CHECK();
+    return MDTILE_OK;
+}
+
 extern "C" int mdtile_silu(const float* d_x, float* d_y, size_t n, mdtile_stream_t stream) {
     MDT_CHECK_ARG(d_x && d_y, "mdtile_silu: null argument");
     if (n == 0) return MDTILE_OK;

@@ -78,6 +78,10 @@ _SIGNATURES = {
     "mdtile_conv_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mdtile_conv2d": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                               c_int, c_int, c_void_p]),
+    "mdtile_gn_coeffs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "mdtile_conv2d_gn_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "mdtile_conv2d_gn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                 c_int, c_int, c_void_p]),
     "mdtile_vae_attn_ws_size": (c_size_t, [c_int, c_int, c_int]),
     "mdtile_vae_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p]),
     "mdtile_crop_store": (c_int, [c_void_p, c_int, c_int, c_int, c_int, _IP, _IP, c_int, c_void_p, c_int, c_int, c_void_p]),
@@ -407,6 +411,22 @@ def gn_apply(x: torch.Tensor, mean: torch.Tensor, var: torch.Tensor, gamma=None,
     return out
 
 
+def gn_coeffs(mean: torch.Tensor, var: torch.Tensor, gamma, beta, C: int, groups: int = 32, eps: float = 1e-6) -> torch.Tensor:
+    """[B, 2, C] per-channel (a, s) of a fixed-statistics GroupNorm: a = gamma / sqrt(var + eps), s = beta - mean * a --
+    the operand of the fused pre-activation conv (`PackedConv.__call__(..., pre_gn=coef)`)."""
+    _dev_tensor(mean, "mean", torch.float32)
+    _dev_tensor(var, "var", torch.float32)
+    B = mean.numel() // groups
+    assert mean.numel() == B * groups and var.numel() == B * groups
+    for nm, t in (("gamma", gamma), ("beta", beta)):
+        if t is not None:
+            _dev_tensor(t, nm, torch.float32)
+            assert t.numel() == C
+    coef = torch.empty((B, 2, C), dtype=torch.float32, device=mean.device)
+    _check(lib().mdtile_gn_coeffs(_p(mean), _p(var), _p(gamma), _p(beta), B, C, groups, eps, _p(coef), _stream()), "mdtile_gn_coeffs")
+    return coef
+
+
 def silu(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _dev_tensor(x, "x", torch.float32)
     out = torch.empty_like(x) if out is None else out
@@ -436,10 +456,17 @@ class PackedConv:
         _check(lib().mdtile_conv_pack(_p(weight), _p(self.packed), self.cout, self.cin, self.ksize, _stream()), "mdtile_conv_pack")
         self.bias = None if bias is None else _dev_tensor(bias.detach().contiguous(), "bias", torch.float32)
 
+    def fuses_pre_gn(self, upsample2x: bool = False, token_major: bool = False, exact: bool = False) -> bool:
+        """True when this conv has a kernel that applies GroupNorm + SiLU to its input on load (mdtile_conv2d_gn)."""
+        flags = (CONV_UPSAMPLE2X if upsample2x else 0) | (CONV_EXACT_F32 if exact else 0)
+        return bool(lib().mdtile_conv2d_gn_supported(self.cout, self.cin, self.ksize, flags, int(token_major)))
+
     def __call__(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, upsample2x: bool = False,
-                 token_major: bool = False, exact: bool = False) -> torch.Tensor:
+                 token_major: bool = False, exact: bool = False, pre_gn: Optional[torch.Tensor] = None) -> torch.Tensor:
         """exact=True forces the exact-fp32 MFMA kernel; by default 3x3 convs with cin % 16 == 0 run on the split-bf16
-        ("bf16x3") matrix-core kernel: fp32 accumulate, ~1e-5 relative to fp32."""
+        ("bf16x3") matrix-core kernel: fp32 accumulate, ~1e-5 relative to fp32.
+        pre_gn = gn_coeffs(...) [B, 2, cin]: y = conv(silu(a * x + s)) -- GroupNorm + SiLU fused into the input staging
+        (only where fuses_pre_gn() says so)."""
         _dev_tensor(x, "x", torch.float32)
         B, cin, H, W = x.shape
         assert cin == self.cin, f"conv expects {self.cin} input channels, got {cin}"
@@ -450,6 +477,12 @@ class PackedConv:
         if residual is not None:
             _dev_tensor(residual, "residual", torch.float32)
             assert residual.shape == y.shape
+        if pre_gn is not None:
+            _dev_tensor(pre_gn, "pre_gn", torch.float32)
+            assert tuple(pre_gn.shape) == (B, 2, self.cin) and not token_major and not upsample2x
+            _check(lib().mdtile_conv2d_gn(_p(x), _p(pre_gn), _p(self.packed), _p(self.bias), _p(residual), _p(y), B, self.cin, self.cout,
+                                          H, W, self.ksize, CONV_EXACT_F32 if exact else 0, _stream()), "mdtile_conv2d_gn")
+            return y
         _check(lib().mdtile_conv2d(_p(x), _p(self.packed), _p(self.bias), _p(residual), _p(y), B, self.cin, self.cout, H, W,
                                    self.ksize, (CONV_UPSAMPLE2X if upsample2x else 0) | (CONV_EXACT_F32 if exact else 0),
                                    int(token_major), _stream()), "mdtile_conv2d")

@@ -30,6 +30,12 @@ from modules.shared import state
 import mdtile
 
 
+import os as _os
+# GroupNorm + SiLU fused into the following 3x3 conv's input staging (engine: mdtile_conv2d_gn).  MDTILE_FUSE_GN=0 keeps the
+# separate one-pass GroupNorm+SiLU kernel (A/B measurements, debugging).
+FUSE_PRE_GN = _os.environ.get("MDTILE_FUSE_GN", "1") != "0"
+
+
 def get_rcmd_enc_tsize() -> int:
     """Upstream picks by VRAM (:79-87); every MI355X has 288 GB, i.e. the top bucket."""
     return 3072 if torch.cuda.is_available() else 512
@@ -154,10 +160,11 @@ class GroupNormParam:
 
 # ---------------------------------------------------------------------------------------------------------------------
 class TileState:
-    __slots__ = ("x", "res", "pc")
+    __slots__ = ("x", "res", "pc", "pre")
 
     def __init__(self, x):
         self.x, self.res, self.pc = x, [], 0
+        self.pre = None   # pending fused pre-activation: gn_coeffs of the norm just resolved, consumed by the next conv
 
 
 class VAEHook:
@@ -222,7 +229,8 @@ class VAEHook:
             if s.kind == "store_res":
                 st.res.append(st.x if s.conv is None else s.conv(st.x))
             elif s.kind == "conv":
-                st.x = s.conv(st.x, residual=st.res.pop() if s.fuse_res else None, upsample2x=s.upsample)
+                st.x = s.conv(st.x, residual=st.res.pop() if s.fuse_res else None, upsample2x=s.upsample, pre_gn=st.pre)
+                st.pre = None
             elif s.kind == "attn":
                 st.x = s.attn(st.x, st.res.pop())
             elif s.kind == "tanh":
@@ -233,8 +241,13 @@ class VAEHook:
     def _apply_norm(steps: List[Step], st: TileState, var: Tensor, mean: Tensor):
         s = steps[st.pc]
         gamma, beta = s.norm
-        keep = st.res and st.res[-1] is st.x          # identity shortcut: the residual aliases the pre-norm tensor
-        st.x = mdtile.gn_apply(st.x, mean, var, gamma, beta, 32, 1e-6, s.silu, out=None if keep else st.x)
+        nxt = steps[st.pc + 1] if st.pc + 1 < len(steps) else None
+        if FUSE_PRE_GN and s.silu and nxt is not None and nxt.kind == "conv" and nxt.conv.fuses_pre_gn(upsample2x=nxt.upsample):
+            # norm + SiLU ride on the conv's input staging: only the per-channel (a, s) pair is formed here
+            st.pre = mdtile.gn_coeffs(mean, var, gamma, beta, st.x.shape[1], 32, 1e-6)
+        else:
+            keep = st.res and st.res[-1] is st.x          # identity shortcut: the residual aliases the pre-norm tensor
+            st.x = mdtile.gn_apply(st.x, mean, var, gamma, beta, 32, 1e-6, s.silu, out=None if keep else st.x)
         st.pc += 1
 
     @torch.no_grad()

@@ -109,8 +109,65 @@ def test_conv2d_vs_torch(plugin, cuda, B, cin, cout, k, H, W, up, res, tok, exac
     assert err < tol, f"conv rel err {err}; worst at {np.unravel_index((out - ref).abs().argmax().item(), ref.shape)}"
 
 
+@pytest.mark.parametrize("B,cin,cout,H,W,res", [
+    (1, 128, 128, 17, 45, True),     # ragged edges, 128-cout block
+    (2, 512, 512, 24, 40, False),    # SD mid-block width, batch 2 (per-sample statistics)
+    (1, 64, 32, 20, 33, True),       # 64-cout block variant
+    (1, 256, 128, 9, 70, False),
+])
+def test_conv2d_fused_groupnorm_silu(plugin, cuda, B, cin, cout, H, W, res):
+    """mdtile_conv2d_gn: y = conv(silu(groupnorm_fixed_stats(x))) (+ residual) with the norm + SiLU applied while the conv
+    stages its input, against the unfused torch chain on given (not self-computed) statistics."""
+    E = plugin.engine
+    torch.manual_seed(cin + cout + H)
+    conv = torch.nn.Conv2d(cin, cout, 3, 1, 1)
+    x = torch.randn(B, cin, H, W) * 1.7 + 0.3
+    mean = torch.randn(B * 32) * 0.2
+    var = torch.rand(B * 32) * 2.0 + 0.3
+    gamma, beta = torch.randn(cin) * 0.5 + 1.0, torch.randn(cin) * 0.3
+    cpg = cin // 32
+    with torch.no_grad():
+        m = mean.view(B, 32, 1, 1, 1)
+        v = var.view(B, 32, 1, 1, 1)
+        xn = ((x.view(B, 32, cpg, H, W) - m) / torch.sqrt(v + 1e-6)).view(B, cin, H, W)
+        xn = F.silu(xn * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1))
+        ref = conv(xn)
+        r = torch.randn_like(ref) if res else None
+        if res:
+            ref = ref + r
+    pc = E.PackedConv(conv.weight.detach().to(cuda), conv.bias.detach().to(cuda))
+    assert pc.fuses_pre_gn()
+    coef = E.gn_coeffs(mean.to(cuda), var.to(cuda), gamma.to(cuda), beta.to(cuda), cin, 32, 1e-6)
+    out = pc(x.to(cuda), residual=None if r is None else r.to(cuda), pre_gn=coef).cpu()
+    err = _rel(out, ref)
+    assert err < 1e-4, f"fused GN+SiLU conv rel err {err}"
+    # and identical (to fp32 round-off of exp / rcp) to the engine's own unfused pair
+    xa = E.gn_apply(x.to(cuda), mean.to(cuda), var.to(cuda), gamma.to(cuda), beta.to(cuda), 32, 1e-6, True)
+    out2 = pc(xa, residual=None if r is None else r.to(cuda)).cpu()
+    assert _rel(out, out2) < 2e-5
+
+
+def test_tiled_decode_fused_norm_matches_unfused(plugin, cuda):
+    dec = ld.make_decoder(3).to(cuda)
+    dec.original_forward = dec.forward
+    torch.manual_seed(9)
+    z = torch.randn(1, 4, 30, 38).to(cuda)
+    outs = {}
+    old = plugin.tilevae.FUSE_PRE_GN
+    try:
+        for fuse in (True, False):
+            plugin.tilevae.FUSE_PRE_GN = fuse
+            for fast in (True, False):
+                hook = plugin.tilevae.VAEHook(dec, 12, is_decoder=True, fast_decoder=fast, fast_encoder=False, color_fix=False)
+                outs[(fuse, fast)] = hook(z).cpu()
+    finally:
+        plugin.tilevae.FUSE_PRE_GN = old
+    for fast in (True, False):
+        assert _rel(outs[(True, fast)], outs[(False, fast)]) < 5e-5
+
+
 @pytest.mark.parametrize("exact", [False, True], ids=["bf16x3", "f32"])
-@pytest.mark.parametrize("B,C,T", [(1, 128, 64), (1, 128, 100), (2, 128, 200), (1, 256, 77), (1, 512, 150), (1, 512, 1000),
+@pytest.mark.parametrize("B,C,T", [(1, 512, 3000), (2, 256, 700), (1, 128, 64), (1, 128, 100), (2, 128, 200), (1, 256, 77), (1, 512, 150), (1, 512, 1000),
                                    (1, 512, 128), (2, 256, 513), (1, 128, 2050)])
 def test_attention_vs_oracle(plugin, cuda, B, C, T, exact):
     E = plugin.engine
