@@ -208,6 +208,15 @@ int mdtile_conv2d_gn_supported(int cout, int cin, int ksize, int flags, int out_
 int mdtile_conv2d_gn(const float* d_x, const float* d_coef, const float* d_w_packed, const float* d_bias, const float* d_residual,
                      float* d_y, int B, int cin, int cout, int H, int W, int ksize, int flags, mdtile_stream_t stream);
 
+/* Row-band pieces of get_var_mean (tilevae.py:207-215) for an activation that is split by rows across GPUs (sequence-parallel
+ * fast-mode estimator): every plane holds plane_stride floats of which [offset, offset+len) are this rank's own rows.
+ *   mdtile_gn_sums      : d_sums[B*groups][2] = fp64 (sum, sum of squares) over the own rows of each (sample, group);
+ *                         d_ws: mdtile_gn_stats_ws_size(B, groups) bytes.  Ranks all-reduce(sum) d_sums.
+ *   mdtile_gn_from_sums : mean = s1/count, var = s2/count - mean^2 (biased), count = elements per (sample, group) over ALL ranks */
+int mdtile_gn_sums(const float* d_x, int B, int C, size_t plane_stride, size_t offset, size_t len, int groups, double* d_sums,
+                   void* d_ws, mdtile_stream_t stream);
+int mdtile_gn_from_sums(const double* d_sums, double count, int BG, float* d_mean, float* d_var, mdtile_stream_t stream);
+
 /* attn_forward body between the 1x1 convs (tile_utils/attn.py:55-70): single head,
  * out[b,c,i] = sum_j v[b,c,j] * softmax_j(scale * sum_c' q[b,c',i] k[b,c',j]).
  * q,k: [B,C,T] channel-major;  v: [B,T,C] token-major (conv out_layout 1);  out: [B,C,T].  C = 128, 256 or 512.
@@ -219,6 +228,11 @@ int mdtile_conv2d_gn(const float* d_x, const float* d_coef, const float* d_w_pac
 size_t mdtile_vae_attn_ws_size(int B, int C, int T);
 int mdtile_vae_attn(const float* d_q, const float* d_k, const float* d_v, float* d_out, int B, int C, int T, float scale,
                     int flags, void* d_ws, mdtile_stream_t stream);
+/* Same contraction with separate query / key token counts: q [B,C,Tq], k [B,C,Tk], v [B,Tk,C] -> out [B,C,Tq]
+ * (a row band of queries against the keys / values gathered from every band).  Split-bf16 kernel; workspace as above. */
+size_t mdtile_vae_attn_qk_ws_size(int B, int C, int Tq, int Tk);
+int mdtile_vae_attn_qk(const float* d_q, const float* d_k, const float* d_v, float* d_out, int B, int C, int Tq, int Tk, float scale,
+                       void* d_ws, mdtile_stream_t stream);
 
 /* crop_valid_region + result[...] = tile (tilevae.py:248-259, 630-632): copies the valid window of one finished tile
  * [N,C,th,tw] into result [N,C,RH,RW].  in_bbox/out_bbox as returned by mdtile_vae_split_tiles. */

@@ -208,9 +208,9 @@ __global__ __launch_bounds__(256) void k_attn(const float* __restrict__ q, const
 // vae_attn_bf16x3.hip
 namespace mdt {
 bool attn_bf16x3_eligible(int C);
-size_t attn_bf16x3_ws_bytes(int B, int C, int T);
-int attn_bf16x3_launch(const float* d_q, const float* d_k, const float* d_v_tok, float* d_out, int B, int C, int T, float scale, void* d_ws,
-                       hipStream_t s);
+size_t attn_bf16x3_ws_bytes(int B, int C, int Tq, int Tk);
+int attn_bf16x3_launch(const float* d_q, const float* d_k, const float* d_v_tok, float* d_out, int B, int C, int Tq, int Tk, float scale,
+                       void* d_ws, hipStream_t s);
 }  // namespace mdt
 
 static bool attn_force_f32() {
@@ -222,7 +222,7 @@ static bool attn_force_f32() {
 // bf16 hi/lo images of q, k and v
 extern "C" size_t mdtile_vae_attn_ws_size(int B, int C, int T) {
     if (B <= 0 || T <= 0 || !attn_bf16x3_eligible(C)) return 0;
-    return attn_bf16x3_ws_bytes(B, C, T);
+    return attn_bf16x3_ws_bytes(B, C, T, T);
 }
 
 extern "C" int mdtile_vae_attn(const float* d_q, const float* d_k, const float* d_v, float* d_out, int B, int C, int T, float scale,
@@ -233,7 +233,7 @@ extern "C" int mdtile_vae_attn(const float* d_q, const float* d_k, const float* 
     hipStream_t s = as_stream(stream);
     if (!(flags & MDTILE_ATTN_EXACT_F32) && !attn_force_f32() && attn_bf16x3_eligible(C)) {
         MDT_CHECK_ARG(d_ws, "mdtile_vae_attn: the split-bf16 path needs the workspace of mdtile_vae_attn_ws_size()");
-        return attn_bf16x3_launch(d_q, d_k, d_v, d_out, B, C, T, scale, d_ws, s);
+        return attn_bf16x3_launch(d_q, d_k, d_v, d_out, B, C, T, T, scale, d_ws, s);
     }
     dim3 grid((T + BM - 1) / BM, B), block(256);
     if (C == 512) hipLaunchKernelGGL(k_attn<4>, grid, block, 0, s, d_q, d_k, d_v, d_out, T, scale);
@@ -241,4 +241,19 @@ extern "C" int mdtile_vae_attn(const float* d_q, const float* d_k, const float* 
     else hipLaunchKernelGGL(k_attn<1>, grid, block, 0, s, d_q, d_k, d_v, d_out, T, scale);
     MDT_LAUNCH_CHECK();
     return MDTILE_OK;
+}
+
+// Queries of one row band against keys / values of the whole image (q [B,C,Tq]; k [B,C,Tk]; v [B,Tk,C]; out [B,C,Tq]):
+// the attention step of the sequence-parallel fast-mode estimator (mdtile/seqpar.py).  Split-bf16 kernel only.
+extern "C" size_t mdtile_vae_attn_qk_ws_size(int B, int C, int Tq, int Tk) {
+    if (B <= 0 || Tq <= 0 || Tk <= 0 || !attn_bf16x3_eligible(C)) return 0;
+    return attn_bf16x3_ws_bytes(B, C, Tq, Tk);
+}
+
+extern "C" int mdtile_vae_attn_qk(const float* d_q, const float* d_k, const float* d_v, float* d_out, int B, int C, int Tq, int Tk,
+                                  float scale, void* d_ws, mdtile_stream_t stream) {
+    MDT_CHECK_ARG(d_q && d_k && d_v && d_out && d_ws, "mdtile_vae_attn_qk: null argument");
+    MDT_CHECK_ARG(B > 0 && B <= 65535 && Tq > 0 && Tk > 0, "mdtile_vae_attn_qk: bad shape B=%d Tq=%d Tk=%d", B, Tq, Tk);
+    MDT_CHECK_ARG(attn_bf16x3_eligible(C), "mdtile_vae_attn_qk: C=%d unsupported (128, 256 or 512)", C);
+    return attn_bf16x3_launch(d_q, d_k, d_v, d_out, B, C, Tq, Tk, scale, d_ws, as_stream(stream));
 }

@@ -100,8 +100,10 @@ __global__ __launch_bounds__(256) void k_attn_prep_v(const float* __restrict__ s
 
 template <int C>
 __global__ __launch_bounds__(512) void k_attn_bf16x3(const u32x4* __restrict__ Qr, const u32x4* __restrict__ Kr, const u32x4* __restrict__ Vr,
-                                                     float* __restrict__ out, int T, int T128, float scale, int nsplit,
+                                                     float* __restrict__ out, int T, int T128, int Tk, int Tk128, float scale, int nsplit,
                                                      float* __restrict__ part, float* __restrict__ pstat) {
+    // T / T128: QUERY tokens (rows of the output); Tk / Tk128: KEY tokens.  They differ only when a row band of the queries
+    // attends to keys / values gathered from every band (sequence-parallel estimator, mdtile/seqpar.py).
     constexpr int NKS = C / 16, NMT = C / 32, NSS = NKS / 2;        // channel k-steps, 32-channel output tiles, score slabs
     constexpr int WAVES_M = NMT < 8 ? NMT : 8, WAVES_N = 8 / WAVES_M, MT_W = NMT / WAVES_M, NT_W = 4 / WAVES_N;
     constexpr int PV_REC = NMT * 2 * 64;                            // records of one V slab (16 keys)
@@ -119,9 +121,9 @@ __global__ __launch_bounds__(512) void k_attn_bf16x3(const u32x4* __restrict__ Q
     const int kt_w = wave >> 1, qh = wave & 1;                      // score phase: key tile, query-tile pair
     const int wm = wave % WAVES_M, wn = wave / WAVES_M;             // output phase: channel tiles, query tiles
     const int b = blockIdx.y, qb = blockIdx.x;
-    const int tiles = T128 / 32, groups = T128 / 16, nkb = T128 / BK;
+    const int tiles = T128 / 32, ktiles = Tk128 / 32, groups = Tk128 / 16, nkb = Tk128 / BK;
     const u32x4* Qb = Qr + (size_t)b * tiles * NKS * 128 + (size_t)qb * 4 * NKS * 128;
-    const u32x4* Kb = Kr + (size_t)b * tiles * NKS * 128;
+    const u32x4* Kb = Kr + (size_t)b * ktiles * NKS * 128;
     const u32x4* Vb = Vr + (size_t)b * groups * NMT * 128;
 
     u32x4 rg[4];
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(512) void k_attn_bf16x3(const u32x4* __restrict__ Q
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = key0 + (r & 3) + 8 * (r >> 2);
-                const float sv = key < T ? st[j][r] * scale : -INFINITY;
+                const float sv = key < Tk ? st[j][r] * scale : -INFINITY;
                 st[j][r] = sv;
                 m = fmaxf(m, sv);
             }
@@ -382,11 +384,11 @@ static int attn_num_cus() {
     }();
     return n;
 }
-static int attn_nsplit(int B, int T) {
+static int attn_nsplit(int B, int Tq, int Tk) {
     static const int forced = [] { const char* e = getenv("MDTILE_ATTN_SPLIT"); return e ? atoi(e) : 0; }();
-    const int nkb = (T + 127) / 128;
+    const int nkb = (Tk + 127) / 128;
     if (forced >= 1 && forced <= 4) return forced <= nkb ? forced : 1;
-    const long long blocks = (long long)B * nkb;
+    const long long blocks = (long long)B * ((Tq + 127) / 128);
     const int cus = attn_num_cus();
     double eff[5], best = 0.0;
     for (int s = 1; s <= 4; ++s) {
@@ -399,47 +401,47 @@ static int attn_nsplit(int B, int T) {
     return 1;
 }
 
-// workspace: Qrec, Krec, Vrec, each B * T128 * C * 4 bytes (hi + lo bf16 per element) [+ nsplit un-normalised parts
-// B*C*T fp32 and their (max, sum) rows 2*B*T128 fp32 when the key range is split]
-size_t attn_bf16x3_ws_bytes(int B, int C, int T) {
-    const size_t T128 = ((size_t)T + 127) / 128 * 128;
-    const int ns = attn_nsplit(B, T);
-    size_t bytes = 3 * (size_t)B * T128 * C * 4;
-    if (ns > 1) bytes += (size_t)ns * ((size_t)B * C * T + 2 * (size_t)B * T128) * 4;
+// workspace: Qrec (B * Tq128 * C * 4 bytes: hi + lo bf16 per element), Krec, Vrec (B * Tk128 * C * 4 bytes each)
+// [+ nsplit un-normalised parts B*C*Tq fp32 and their (max, sum) rows 2*B*Tq128 fp32 when the key range is split]
+size_t attn_bf16x3_ws_bytes(int B, int C, int Tq, int Tk) {
+    const size_t Tq128 = ((size_t)Tq + 127) / 128 * 128, Tk128 = ((size_t)Tk + 127) / 128 * 128;
+    const int ns = attn_nsplit(B, Tq, Tk);
+    size_t bytes = (size_t)B * (Tq128 + 2 * Tk128) * C * 4;
+    if (ns > 1) bytes += (size_t)ns * ((size_t)B * C * Tq + 2 * (size_t)B * Tq128) * 4;
     return bytes;
 }
 
-int attn_bf16x3_launch(const float* d_q, const float* d_k, const float* d_v_tok, float* d_out, int B, int C, int T, float scale, void* d_ws,
-                       hipStream_t s) {
-    const int T128 = (T + 127) / 128 * 128;
-    const size_t per = (size_t)B * T128 * C * 4 / 16;   // records per operand
+int attn_bf16x3_launch(const float* d_q, const float* d_k, const float* d_v_tok, float* d_out, int B, int C, int Tq, int Tk, float scale,
+                       void* d_ws, hipStream_t s) {
+    const int Tq128 = (Tq + 127) / 128 * 128, Tk128 = (Tk + 127) / 128 * 128;
+    const size_t perq = (size_t)B * Tq128 * C * 4 / 16, perk = (size_t)B * Tk128 * C * 4 / 16;   // records per operand
     u32x4* Qr = (u32x4*)d_ws;
-    u32x4* Kr = Qr + per;
-    u32x4* Vr = Kr + per;
-    const int ns = attn_nsplit(B, T);
-    float* part = (float*)(Vr + per);
-    float* pstat = part + (size_t)ns * B * C * T;
-    const int tiles = T128 / 32, groups = T128 / 16;
+    u32x4* Kr = Qr + perq;
+    u32x4* Vr = Kr + perk;
+    const int ns = attn_nsplit(B, Tq, Tk);
+    float* part = (float*)(Vr + perk);
+    float* pstat = part + (size_t)ns * B * C * Tq;
     {
-        const size_t n = (size_t)tiles * (C / 16) * 64;
-        dim3 grid(cdiv((long long)n, 256), B);
-        hipLaunchKernelGGL(k_attn_prep_qk, grid, dim3(256), 0, s, d_q, Qr, C, T, tiles);
-        hipLaunchKernelGGL(k_attn_prep_qk, grid, dim3(256), 0, s, d_k, Kr, C, T, tiles);
+        const int qtiles = Tq128 / 32, ktiles = Tk128 / 32;
+        const size_t nq = (size_t)qtiles * (C / 16) * 64, nk = (size_t)ktiles * (C / 16) * 64;
+        hipLaunchKernelGGL(k_attn_prep_qk, dim3(cdiv((long long)nq, 256), B), dim3(256), 0, s, d_q, Qr, C, Tq, qtiles);
+        hipLaunchKernelGGL(k_attn_prep_qk, dim3(cdiv((long long)nk, 256), B), dim3(256), 0, s, d_k, Kr, C, Tk, ktiles);
     }
     {
+        const int groups = Tk128 / 16;
         const size_t n = (size_t)groups * (C / 32) * 64;
         dim3 grid(cdiv((long long)n, 256), B);
-        hipLaunchKernelGGL(k_attn_prep_v, grid, dim3(256), 0, s, d_v_tok, Vr, C, T, groups);
+        hipLaunchKernelGGL(k_attn_prep_v, grid, dim3(256), 0, s, d_v_tok, Vr, C, Tk, groups);
     }
     MDT_LAUNCH_CHECK();
-    dim3 grid(T128 / BQ, B, ns), block(512);
-    if (C == 512) hipLaunchKernelGGL(k_attn_bf16x3<512>, grid, block, 0, s, Qr, Kr, Vr, d_out, T, T128, scale, ns, part, pstat);
-    else if (C == 256) hipLaunchKernelGGL(k_attn_bf16x3<256>, grid, block, 0, s, Qr, Kr, Vr, d_out, T, T128, scale, ns, part, pstat);
-    else hipLaunchKernelGGL(k_attn_bf16x3<128>, grid, block, 0, s, Qr, Kr, Vr, d_out, T, T128, scale, ns, part, pstat);
+    dim3 grid(Tq128 / BQ, B, ns), block(512);
+    if (C == 512) hipLaunchKernelGGL(k_attn_bf16x3<512>, grid, block, 0, s, Qr, Kr, Vr, d_out, Tq, Tq128, Tk, Tk128, scale, ns, part, pstat);
+    else if (C == 256) hipLaunchKernelGGL(k_attn_bf16x3<256>, grid, block, 0, s, Qr, Kr, Vr, d_out, Tq, Tq128, Tk, Tk128, scale, ns, part, pstat);
+    else hipLaunchKernelGGL(k_attn_bf16x3<128>, grid, block, 0, s, Qr, Kr, Vr, d_out, Tq, Tq128, Tk, Tk128, scale, ns, part, pstat);
     MDT_LAUNCH_CHECK();
     if (ns > 1) {
-        dim3 cgrid(cdiv(T, 256), C < 64 ? C : 64, B);
-        hipLaunchKernelGGL(k_attn_combine, cgrid, dim3(256), 0, s, part, pstat, d_out, B, C, T, T128, ns);
+        dim3 cgrid(cdiv(Tq, 256), C < 64 ? C : 64, B);
+        hipLaunchKernelGGL(k_attn_combine, cgrid, dim3(256), 0, s, part, pstat, d_out, B, C, Tq, Tq128, ns);
         MDT_LAUNCH_CHECK();
     }
     return MDTILE_OK;

@@ -75,6 +75,51 @@ __global__ void k_gn_final(const double* __restrict__ part, size_t L, int BG, fl
     var[g] = (float)v;
 }
 
+// Row-band variant for the sequence-parallel estimator: the (sample, group) covers `cpg` planes of `plane_stride` floats, of
+// which only [off, off + len) of every plane (this rank's own rows, halo rows excluded) enter the sums.  Output = the raw
+// fp64 (sum, sum of squares) per group: ranks all-reduce them and finish with k_gn_from_sums.
+__global__ __launch_bounds__(256) void k_gn_partial_rows(const float* __restrict__ x, int cpg, size_t plane_stride, size_t off, size_t len,
+                                                         double* __restrict__ part) {
+    __shared__ double sh[4];
+    const int g = blockIdx.y, blk = blockIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int p = 0; p < cpg; ++p) {
+        const float* base = x + ((size_t)g * cpg + p) * plane_stride + off;
+        for (size_t i = (size_t)blk * 256 + threadIdx.x; i < len; i += (size_t)GN_NBLK * 256) {
+            const double v = base[i];
+            s1 += v; s2 += v * v;
+        }
+    }
+    s1 = block_sum_f64(s1, sh);
+    s2 = block_sum_f64(s2, sh);
+    if (threadIdx.x == 0) {
+        part[((size_t)g * GN_NBLK + blk) * 2 + 0] = s1;
+        part[((size_t)g * GN_NBLK + blk) * 2 + 1] = s2;
+    }
+}
+
+__global__ void k_gn_sum_partials(const double* __restrict__ part, int BG, double* __restrict__ sums) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= BG) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < GN_NBLK; ++b) {
+        s1 += part[((size_t)g * GN_NBLK + b) * 2 + 0];
+        s2 += part[((size_t)g * GN_NBLK + b) * 2 + 1];
+    }
+    sums[(size_t)g * 2 + 0] = s1;
+    sums[(size_t)g * 2 + 1] = s2;
+}
+
+__global__ void k_gn_from_sums(const double* __restrict__ sums, double count, int BG, float* __restrict__ mean, float* __restrict__ var) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= BG) return;
+    const double m = sums[(size_t)g * 2] / count;
+    double v = sums[(size_t)g * 2 + 1] / count - m * m;   // biased, as k_gn_final
+    if (v < 0.0) v = 0.0;
+    mean[g] = (float)m;
+    var[g] = (float)v;
+}
+
 // tilevae.py:320-335: p_i = (px_i / max px) / sum(px_j / max px); var = sum p_i var_i; mean = sum p_i mean_i  (fp32)
 __global__ void k_gn_pool(const float* __restrict__ means, const float* __restrict__ vars, const float* __restrict__ p, int T,
                           int BG, float* __restrict__ mean, float* __restrict__ var) {
@@ -231,6 +276,27 @@ extern "C" int mdtile_gn_stats(const float* d_x, int B, int C, int HW, int group
     hipLaunchKernelGGL(k_gn_partial, dim3(GN_NBLK, BG), dim3(256), 0, s, d_x, L, (double*)d_ws);
     MDT_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_gn_final, dim3(cdiv(BG, 64)), dim3(64), 0, s, (const double*)d_ws, L, BG, d_mean, d_var);
+    MDT_LAUNCH_CHECK();
+    return MDTILE_OK;
+}
+
+extern "C" int mdtile_gn_sums(const float* d_x, int B, int C, size_t plane_stride, size_t offset, size_t len, int groups, double* d_sums,
+                              void* d_ws, mdtile_stream_t stream) {
+    MDT_CHECK_ARG(d_x && d_sums && d_ws, "mdtile_gn_sums: null argument");
+    MDT_CHECK_ARG(B > 0 && C > 0 && len > 0 && offset + len <= plane_stride && groups > 0 && C % groups == 0 && B * groups <= 65535,
+                  "mdtile_gn_sums: bad shape B=%d C=%d groups=%d", B, C, groups);
+    const int BG = B * groups;
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(k_gn_partial_rows, dim3(GN_NBLK, BG), dim3(256), 0, s, d_x, C / groups, plane_stride, offset, len, (double*)d_ws);
+    MDT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_gn_sum_partials, dim3(cdiv(BG, 64)), dim3(64), 0, s, (const double*)d_ws, BG, d_sums);
+    MDT_LAUNCH_CHECK();
+    return MDTILE_OK;
+}
+
+extern "C" int mdtile_gn_from_sums(const double* d_sums, double count, int BG, float* d_mean, float* d_var, mdtile_stream_t stream) {
+    MDT_CHECK_ARG(d_sums && d_mean && d_var && BG > 0 && count > 0.0, "mdtile_gn_from_sums: bad arguments");
+    hipLaunchKernelGGL(k_gn_from_sums, dim3(cdiv(BG, 64)), dim3(64), 0, as_stream(stream), d_sums, count, BG, d_mean, d_var);
     MDT_LAUNCH_CHECK();
     return MDTILE_OK;
 }

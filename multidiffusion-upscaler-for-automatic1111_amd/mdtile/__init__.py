@@ -10,7 +10,7 @@ from __future__ import annotations
 import ctypes
 import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_size_t, c_void_p
-from typing import List, Optional, Sequence
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 
@@ -78,6 +78,10 @@ _SIGNATURES = {
     "mdtile_conv_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mdtile_conv2d": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                               c_int, c_int, c_void_p]),
+    "mdtile_gn_sums": (c_int, [c_void_p, c_int, c_int, c_size_t, c_size_t, c_size_t, c_int, c_void_p, c_void_p, c_void_p]),
+    "mdtile_gn_from_sums": (c_int, [c_void_p, ctypes.c_double, c_int, c_void_p, c_void_p, c_void_p]),
+    "mdtile_vae_attn_qk_ws_size": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "mdtile_vae_attn_qk": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "mdtile_gn_coeffs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "mdtile_conv2d_gn_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "mdtile_conv2d_gn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
@@ -411,6 +415,28 @@ def gn_apply(x: torch.Tensor, mean: torch.Tensor, var: torch.Tensor, gamma=None,
     return out
 
 
+def gn_sums(x: torch.Tensor, row_lo: int, row_hi: int, groups: int = 32) -> torch.Tensor:
+    """fp64 [B*groups, 2] (sum, sum of squares) over rows [row_lo, row_hi) of every plane of x [B, C, H, W] (the rows a rank
+    owns; halo rows excluded).  Piece of get_var_mean (tilevae.py:207-215) for a row-split activation."""
+    _dev_tensor(x, "x", torch.float32)
+    B, C, H, W = x.shape
+    assert 0 <= row_lo < row_hi <= H
+    sums = torch.empty((B * groups, 2), dtype=torch.float64, device=x.device)
+    ws = torch.empty(lib().mdtile_gn_stats_ws_size(B, groups) // 8, dtype=torch.float64, device=x.device)
+    _check(lib().mdtile_gn_sums(_p(x), B, C, H * W, row_lo * W, (row_hi - row_lo) * W, groups, _p(sums), _p(ws), _stream()), "mdtile_gn_sums")
+    return sums
+
+
+def gn_from_sums(sums: torch.Tensor, count: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(var, mean) from all-reduced fp64 sums; count = elements per (sample, group) over every rank."""
+    _dev_tensor(sums, "sums", torch.float64)
+    BG = sums.shape[0]
+    mean = torch.empty(BG, dtype=torch.float32, device=sums.device)
+    var = torch.empty_like(mean)
+    _check(lib().mdtile_gn_from_sums(_p(sums), float(count), BG, _p(mean), _p(var), _stream()), "mdtile_gn_from_sums")
+    return var, mean
+
+
 def gn_coeffs(mean: torch.Tensor, var: torch.Tensor, gamma, beta, C: int, groups: int = 32, eps: float = 1e-6) -> torch.Tensor:
     """[B, 2, C] per-channel (a, s) of a fixed-statistics GroupNorm: a = gamma / sqrt(var + eps), s = beta - mean * a --
     the operand of the fused pre-activation conv (`PackedConv.__call__(..., pre_gn=coef)`)."""
@@ -502,6 +528,20 @@ def vae_attn(q: torch.Tensor, k: torch.Tensor, v_tok: torch.Tensor, scale: float
     ws = torch.empty(max(1, (ws_bytes + 3) // 4), dtype=torch.float32, device=q.device)
     _check(lib().mdtile_vae_attn(_p(q), _p(k), _p(v_tok), _p(out), B, C, T, scale, ATTN_EXACT_F32 if exact else 0, _p(ws), _stream()),
            "mdtile_vae_attn")
+    return out
+
+
+def vae_attn_qk(q: torch.Tensor, k: torch.Tensor, v_tok: torch.Tensor, scale: float) -> torch.Tensor:
+    """Attention of a band of queries q [B,C,Tq] against keys k [B,C,Tk] / values v_tok [B,Tk,C]; returns [B,C,Tq]."""
+    _dev_tensor(q, "q", torch.float32)
+    _dev_tensor(k, "k", torch.float32)
+    _dev_tensor(v_tok, "v", torch.float32)
+    B, C, Tq = q.shape
+    Tk = k.shape[2]
+    assert k.shape[:2] == (B, C) and tuple(v_tok.shape) == (B, Tk, C)
+    out = torch.empty_like(q)
+    ws = torch.empty(max(1, (lib().mdtile_vae_attn_qk_ws_size(B, C, Tq, Tk) + 3) // 4), dtype=torch.float32, device=q.device)
+    _check(lib().mdtile_vae_attn_qk(_p(q), _p(k), _p(v_tok), _p(out), B, C, Tq, Tk, scale, _p(ws), _stream()), "mdtile_vae_attn_qk")
     return out
 
 

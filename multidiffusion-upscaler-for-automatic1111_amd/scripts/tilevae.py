@@ -34,6 +34,9 @@ import os as _os
 # GroupNorm + SiLU fused into the following 3x3 conv's input staging (engine: mdtile_conv2d_gn).  MDTILE_FUSE_GN=0 keeps the
 # separate one-pass GroupNorm+SiLU kernel (A/B measurements, debugging).
 FUSE_PRE_GN = _os.environ.get("MDTILE_FUSE_GN", "1") != "0"
+# multi-GPU fast mode: run the GroupNorm estimator sequence-parallel across the ranks (mdtile/seqpar.py); 0 = every rank
+# repeats the whole estimator (no communication, but 1 of every rank's ~3 work units at 8 GPUs)
+SP_ESTIMATOR = _os.environ.get("MDTILE_SP_ESTIMATOR", "1") != "0"
 
 
 def get_rcmd_enc_tsize() -> int:
@@ -60,8 +63,9 @@ class Step:
 class AttnPack:
     """q/k/v/proj_out of one AttnBlock, packed for the engine; v is produced token-major for the PV contraction."""
 
-    def __init__(self, attn):
-        self.q, self.k, self.v, self.proj = (_pack(attn.q), _pack(attn.k), _pack(attn.v), _pack(attn.proj_out))
+    def __init__(self, attn, pack=None):
+        pack = pack or _pack
+        self.q, self.k, self.v, self.proj = (pack(attn.q), pack(attn.k), pack(attn.v), pack(attn.proj_out))
         self.channels = attn.q.weight.shape[0]
 
     def __call__(self, h: Tensor, residual: Tensor) -> Tensor:
@@ -88,36 +92,39 @@ def _norm_params(gn):
     return g, b
 
 
-def _resblock(steps: List[Step], blk):
+def _resblock(steps: List[Step], blk, pack):
     if blk.in_channels != blk.out_channels:
         shortcut = blk.conv_shortcut if blk.use_conv_shortcut else blk.nin_shortcut
-        steps.append(Step("store_res", conv=_pack(shortcut)))
+        steps.append(Step("store_res", conv=pack(shortcut)))
     else:
         steps.append(Step("store_res"))
     steps.append(Step("norm", norm=_norm_params(blk.norm1), silu=True))
-    steps.append(Step("conv", conv=_pack(blk.conv1)))
+    steps.append(Step("conv", conv=pack(blk.conv1)))
     steps.append(Step("norm", norm=_norm_params(blk.norm2), silu=True))
-    steps.append(Step("conv", conv=_pack(blk.conv2), fuse_res=True))       # conv2 + add_res in one epilogue
+    steps.append(Step("conv", conv=pack(blk.conv2), fuse_res=True))       # conv2 + add_res in one epilogue
 
 
-def build_task_queue(net, is_decoder: bool = True) -> List[Step]:
+def build_task_queue(net, is_decoder: bool = True, pack=None) -> List[Step]:
     """Linearise an ldm Decoder exactly in upstream's order (:139-195): conv_in, mid(res, attn, res), levels top-down
-    with num_res_blocks+1 resblocks (+ upsample except on level 0), norm_out, silu, conv_out.  30 norms for SD/SDXL."""
+    with num_res_blocks+1 resblocks (+ upsample except on level 0), norm_out, silu, conv_out.  30 norms for SD/SDXL.
+    `pack` turns an nn.Conv2d into the callable a step carries (default: engine weights, mdtile.PackedConv; the CPU tests
+    of the multi-GPU host logic inject their own)."""
     if not is_decoder:
         raise NotImplementedError("mdtile engine: the encoder direction is not built yet")
-    steps = [Step("conv", conv=_pack(net.conv_in))]
-    _resblock(steps, net.mid.block_1)
+    pack = pack or _pack
+    steps = [Step("conv", conv=pack(net.conv_in))]
+    _resblock(steps, net.mid.block_1, pack)
     steps += [Step("store_res"), Step("norm", norm=_norm_params(net.mid.attn_1.norm)),
-              Step("attn", attn=AttnPack(net.mid.attn_1))]
-    _resblock(steps, net.mid.block_2)
+              Step("attn", attn=AttnPack(net.mid.attn_1, pack))]
+    _resblock(steps, net.mid.block_2, pack)
     for lvl in reversed(range(net.num_resolutions)):
         for i in range(net.num_res_blocks + 1):
-            _resblock(steps, net.up[lvl].block[i])
+            _resblock(steps, net.up[lvl].block[i], pack)
         if lvl != 0:
-            steps.append(Step("conv", conv=_pack(net.up[lvl].upsample.conv), upsample=True))  # nearest-2x fused
+            steps.append(Step("conv", conv=pack(net.up[lvl].upsample.conv), upsample=True))  # nearest-2x fused
     if not net.give_pre_end:
         steps.append(Step("norm", norm=_norm_params(net.norm_out), silu=True))
-        steps.append(Step("conv", conv=_pack(net.conv_out)))
+        steps.append(Step("conv", conv=pack(net.conv_out)))
         if net.tanh_out:
             steps.append(Step("tanh"))
     return steps
@@ -310,7 +317,13 @@ class VAEHook:
         if self.fast_mode:
             zs = mdtile.vae_fast_input(z, self.tile_size)
             print(f"[Tiled VAE]: Fast mode enabled, estimating group norm parameters on {zs.shape[3]} x {zs.shape[2]} image")
-            frozen = self.estimate_group_norm(zs, steps)
+            rank, world = self.shard
+            if world > 1 and SP_ESTIMATOR and zs.shape[2] >= 2 * world:
+                # the estimator is one untiled pass: split it by rows across the ranks instead of repeating it on each
+                from mdtile import seqpar
+                frozen = seqpar.estimate_group_norm_sp(steps, zs, seqpar.BandComm(rank, world), seqpar.EngineOps(), FUSE_PRE_GN)
+            else:
+                frozen = self.estimate_group_norm(zs, steps)
 
         rank, world = self.shard
         mine = list(range(len(in_bboxes))) if world == 1 else list(range(rank, len(in_bboxes), world))
