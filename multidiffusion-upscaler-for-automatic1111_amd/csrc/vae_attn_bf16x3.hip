@@ -98,7 +98,11 @@ __global__ __launch_bounds__(256) void k_attn_prep_v(const float* __restrict__ s
     d[64 + lane] = lo;
 }
 
-template <int C>
+// DMA = true: the K/Q/V slabs go global -> LDS directly (global_load_lds_dwordx4: the fragment-order records are straight
+// copies, so a wave's 64 records land as one contiguous 1 KiB run); no staging VGPRs and no ds_write_b128 pass (13 LDS cycles
+// per wave-instruction on the store path -- the score phase was LDS-write bound).  Same two-buffer schedule: the DMA of
+// slab i+1 is issued right after the barrier that opens slab i and is drained (vmcnt(0)) before the barrier that opens i+1.
+template <int C, bool DMA>
 __global__ __launch_bounds__(512) void k_attn_bf16x3(const u32x4* __restrict__ Qr, const u32x4* __restrict__ Kr, const u32x4* __restrict__ Vr,
                                                      float* __restrict__ out, int T, int T128, int Tk, int Tk128, float scale, int nsplit,
                                                      float* __restrict__ part, float* __restrict__ pstat) {
@@ -126,31 +130,50 @@ __global__ __launch_bounds__(512) void k_attn_bf16x3(const u32x4* __restrict__ Q
     const u32x4* Kb = Kr + (size_t)b * ktiles * NKS * 128;
     const u32x4* Vb = Vr + (size_t)b * groups * NMT * 128;
 
-    u32x4 rg[4];
-    // score slab s of key block kb: records [K | Q][tile 4][ks 2][hl][lane]; source = 4 + 4 runs of 256 contiguous records
-    auto issue_S = [&](int kb, int s) {
+    u32x4 rg[DMA ? 1 : 4];
+    // score slab s of key block kb: records [K | Q][tile 4][ks 2][hl][lane]; source = 4 + 4 runs of 256 contiguous records.
+    // `into`: the slab buffer the data is meant for (DMA writes it now; the register path writes it in write_S/V).
+    auto issue_S = [&](int kb, int s, int into) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = tid + 512 * i;                 // i < 2: K part, i >= 2: Q part (compile-time)
             const int rr = r & 1023, t4 = rr >> 8, off = rr & 255;
             const u32x4* src = (i < 2 ? Kb + ((size_t)(kb * 4 + t4) * NKS + 2 * s) * 128 : Qb + ((size_t)t4 * NKS + 2 * s) * 128) + off;
-            rg[i] = *src;
+            if (DMA)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(slab + into * SLAB_REC + wave * 64 + 512 * i), 16, 0, 0);
+            else
+                rg[DMA ? 0 : i] = *src;
         }
     };
-    auto issue_V = [&](int kb, int p) {
+    auto issue_V = [&](int kb, int p, int into) {
         const u32x4* src = Vb + (size_t)(kb * 8 + p) * NMT * 128;
 #pragma unroll
         for (int i = 0; i < NVREG; ++i)
-            if (wave * 64 + 512 * i < PV_REC) rg[i] = src[tid + 512 * i];
+            if (wave * 64 + 512 * i < PV_REC) {
+                if (DMA)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + tid + 512 * i),
+                                                     (__attribute__((address_space(3))) void*)(slab + into * SLAB_REC + wave * 64 + 512 * i), 16, 0, 0);
+                else
+                    rg[DMA ? 0 : i] = src[tid + 512 * i];
+            }
     };
     auto write_S = [&](int buf) {
+        if (DMA) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): this wave's share of the slab has landed in LDS
+            return;
+        }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) slab[buf * SLAB_REC + tid + 512 * i] = rg[i];
+        for (int i = 0; i < 4; ++i) slab[buf * SLAB_REC + tid + 512 * i] = rg[DMA ? 0 : i];
     };
     auto write_V = [&](int buf) {
+        if (DMA) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NVREG; ++i)
-            if (wave * 64 + 512 * i < PV_REC) slab[buf * SLAB_REC + tid + 512 * i] = rg[i];
+            if (wave * 64 + 512 * i < PV_REC) slab[buf * SLAB_REC + tid + 512 * i] = rg[DMA ? 0 : i];
     };
 
     f32x16 acc_o[MT_W][NT_W];
@@ -168,7 +191,7 @@ __global__ __launch_bounds__(512) void k_attn_bf16x3(const u32x4* __restrict__ Q
     const int split = blockIdx.z;
     const int kb_lo = (int)((long long)nkb * split / nsplit), kb_hi = (int)((long long)nkb * (split + 1) / nsplit);
     int buf = 0;
-    issue_S(kb_lo, 0);
+    issue_S(kb_lo, 0, 0);
     for (int kb = kb_lo; kb < kb_hi; ++kb) {
         // ------------------------------------------------ scores: St tiles (kt_w, 2*qh + j), all channels
         f32x16 st[2];
@@ -180,8 +203,8 @@ __global__ __launch_bounds__(512) void k_attn_bf16x3(const u32x4* __restrict__ Q
         for (int s = 0; s < NSS; ++s) {
             write_S(buf);
             __syncthreads();
-            if (s + 1 < NSS) issue_S(kb, s + 1);
-            else issue_V(kb, 0);
+            if (s + 1 < NSS) issue_S(kb, s + 1, buf ^ 1);
+            else issue_V(kb, 0, buf ^ 1);
             const u32x4* sl = slab + buf * SLAB_REC;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -270,8 +293,8 @@ __global__ __launch_bounds__(512) void k_attn_bf16x3(const u32x4* __restrict__ Q
         for (int p = 0; p < 8; ++p) {
             write_V(buf);
             __syncthreads();
-            if (p + 1 < 8) issue_V(kb, p + 1);
-            else if (kb + 1 < kb_hi) issue_S(kb + 1, 0);
+            if (p + 1 < 8) issue_V(kb, p + 1, buf ^ 1);
+            else if (kb + 1 < kb_hi) issue_S(kb + 1, 0, buf ^ 1);
             const u32x4* sl = slab + buf * SLAB_REC;
             bf16x8 vh[MT_W], vl[MT_W];
 #pragma unroll
@@ -435,9 +458,19 @@ int attn_bf16x3_launch(const float* d_q, const float* d_k, const float* d_v_tok,
     }
     MDT_LAUNCH_CHECK();
     dim3 grid(Tq128 / BQ, B, ns), block(512);
-    if (C == 512) hipLaunchKernelGGL(k_attn_bf16x3<512>, grid, block, 0, s, Qr, Kr, Vr, d_out, Tq, Tq128, Tk, Tk128, scale, ns, part, pstat);
-    else if (C == 256) hipLaunchKernelGGL(k_attn_bf16x3<256>, grid, block, 0, s, Qr, Kr, Vr, d_out, Tq, Tq128, Tk, Tk128, scale, ns, part, pstat);
-    else hipLaunchKernelGGL(k_attn_bf16x3<128>, grid, block, 0, s, Qr, Kr, Vr, d_out, Tq, Tq128, Tk, Tk128, scale, ns, part, pstat);
+    // slab transport: direct global -> LDS DMA (default) or global -> VGPR -> ds_write (MDTILE_ATTN_DMA=0)
+    static const bool dma = [] { const char* e = getenv("MDTILE_ATTN_DMA"); return !(e && strcmp(e, "0") == 0); }();
+#define MDT_ATTN_LAUNCH(CC, DD) hipLaunchKernelGGL((k_attn_bf16x3<CC, DD>), grid, block, 0, s, Qr, Kr, Vr, d_out, Tq, Tq128, Tk, Tk128, scale, ns, part, pstat)
+    if (dma) {
+        if (C == 512) MDT_ATTN_LAUNCH(512, true);
+        else if (C == 256) MDT_ATTN_LAUNCH(256, true);
+        else MDT_ATTN_LAUNCH(128, true);
+    } else {
+        if (C == 512) MDT_ATTN_LAUNCH(512, false);
+        else if (C == 256) MDT_ATTN_LAUNCH(256, false);
+        else MDT_ATTN_LAUNCH(128, false);
+    }
+#undef MDT_ATTN_LAUNCH
     MDT_LAUNCH_CHECK();
     if (ns > 1) {
         dim3 cgrid(cdiv(Tq, 256), C < 64 ? C : 64, B);

@@ -217,13 +217,20 @@ int conv_bf16x3_pack(const float* d_w_oihw, void* d_out, int cout, int cin, hipS
 bool conv_bf16x3_gn_supported(int cout, int cin, int ksize, int up);
 int conv_bf16x3_launch(const float* d_x, const void* d_w_rec, const float* d_bias, const float* d_res, float* d_y, int B, int cin,
                        int cout, int H, int W, int up, const float* d_coef, hipStream_t s);
+// vae_conv1x1_bf16x3.hip
+bool conv1x1_bf16x3_eligible(int cout, int cin);
+size_t conv1x1_bf16x3_packed_floats(int cout, int cin);
+int conv1x1_bf16x3_pack(const float* d_w_oihw, void* d_out, int cout, int cin, hipStream_t s);
+int conv1x1_bf16x3_launch(const float* d_x, const void* d_w_rec, const float* d_bias, const float* d_res, float* d_y, int B, int cin,
+                          int cout, size_t HW, hipStream_t s);
 }  // namespace mdt
 
-// packed buffer = [ fp32 image (tap, cin, coutP) | split-bf16 record image (only for shapes the bf16x3 kernel takes) ]
+// packed buffer = [ fp32 image (tap, cin, coutP) | split-bf16 record image (only for shapes the bf16x3 kernels take) ]
 static size_t f32_packed_floats(int cout, int cin, int ksize) { return ((size_t)ksize * ksize * cin * round_up(cout, 32) + 3) & ~(size_t)3; }
 
 extern "C" size_t mdtile_conv_packed_size(int cout, int cin, int ksize) {
     if (cout <= 0 || cin <= 0 || (ksize != 1 && ksize != 3)) return 0;
+    if (ksize == 1) return f32_packed_floats(cout, cin, ksize) + (conv1x1_bf16x3_eligible(cout, cin) ? conv1x1_bf16x3_packed_floats(cout, cin) : 0);
     return f32_packed_floats(cout, cin, ksize) + (conv_bf16x3_eligible(cout, cin, ksize) ? conv_bf16x3_packed_floats(cout, cin) : 0);
 }
 
@@ -233,6 +240,8 @@ extern "C" int mdtile_conv_pack(const float* d_w_oihw, float* d_w_packed, int co
     const size_t n = (size_t)ksize * ksize * cin * CoutP;
     hipLaunchKernelGGL(k_conv_pack, dim3(cdiv((long long)n, 256)), dim3(256), 0, as_stream(stream), d_w_oihw, d_w_packed, cout, cin, ksize, CoutP);
     MDT_LAUNCH_CHECK();
+    if (ksize == 1 && conv1x1_bf16x3_eligible(cout, cin))
+        return conv1x1_bf16x3_pack(d_w_oihw, d_w_packed + f32_packed_floats(cout, cin, ksize), cout, cin, as_stream(stream));
     if (conv_bf16x3_eligible(cout, cin, ksize))
         return conv_bf16x3_pack(d_w_oihw, d_w_packed + f32_packed_floats(cout, cin, ksize), cout, cin, as_stream(stream));
     return MDTILE_OK;
@@ -256,6 +265,11 @@ extern "C" int mdtile_conv2d(const float* d_x, const float* d_w_packed, const fl
     static const bool force_f32 = [] { const char* e = getenv("MDTILE_CONV_MODE"); return e && strcmp(e, "f32") == 0; }();
     if (!force_f32 && !(flags & MDTILE_CONV_EXACT_F32) && out_layout == 0 && conv_bf16x3_eligible(cout, cin, ksize))
         return conv_bf16x3_launch(d_x, d_w_packed + f32_packed_floats(cout, cin, ksize), d_bias, d_residual, d_y, B, cin, cout, H, W, up, nullptr, s);
+    // 1x1 convs (nin_shortcut, q / k / proj_out): split-bf16 kernel over the flat pixel run; MDTILE_CONV1X1=f32 keeps the exact kernel
+    static const bool c1_f32 = [] { const char* e = getenv("MDTILE_CONV1X1"); return e && strcmp(e, "f32") == 0; }();
+    if (ksize == 1 && !up && !force_f32 && !c1_f32 && !(flags & MDTILE_CONV_EXACT_F32) && out_layout == 0 && conv1x1_bf16x3_eligible(cout, cin))
+        return conv1x1_bf16x3_launch(d_x, d_w_packed + f32_packed_floats(cout, cin, ksize), d_bias, d_residual, d_y, B, cin, cout,
+                                     (size_t)H * W, s);
     const bool wide = P.CoutP > 64;
     if (ksize == 3) {
         if (wide) return launch_conv<3, 8, 2, 2, 4, 2>(P, out_layout, s);

@@ -580,9 +580,10 @@ int conv_bf16x3_launch(const float* d_x, const void* d_w_rec, const float* d_bia
         MDT_LAUNCH_CHECK();
         return MDTILE_OK;
     }
-    // pixel rows per block: 8 (default) or 16 (MDTILE_CONV_TH=16: 2x the MFMAs per barrier and per weight stage, MT = 4 only)
+    // pixel rows per block: 16 for the 128-cout blocks (2x the MFMAs per barrier and per weight stage: measured +3..10 %
+    // over 8 rows on the decoder's shapes, profiles/r1e/conv_probe_r1e.log), 8 otherwise or with MDTILE_CONV_TH=8
     static const int th_env = [] { const char* e = getenv("MDTILE_CONV_TH"); return e ? atoi(e) : 0; }();
-    const int th = (MT == 4 && th_env == 16 && H >= 16) ? 16 : TH;
+    const int th = (MT == 4 && th_env != 8 && H >= 16) ? 16 : TH;
     P.PX = (W + TW - 1) / TW;
     P.ptiles = P.PX * ((H + th - 1) / th);
     P.NCB = round_up_i(cout, MT * 32) / (MT * 32);

@@ -78,7 +78,11 @@ CONV_CASES = [  # B, cin, cout, k, H, W, upsample, residual, token_major
     (1, 48, 160, 3, 11, 33, False, False, False),    # cin = 3 K-steps, cout padded 160 -> 256
     (1, 512, 512, 3, 74, 100, True, False, False),   # sub-pixel upsample conv: ragged input tiles (37 x 50), 4 cout blocks
     (1, 64, 64, 3, 18, 66, True, True, False),       # sub-pixel upsample conv, 64-cout block variant + residual
-    (1, 256, 256, 3, 50, 70, False, False, False),   # 16-row blocks when MDTILE_CONV_TH=16
+    (1, 256, 256, 3, 50, 70, False, False, False),   # 16-row blocks (default for 128-cout blocks)
+    (2, 512, 256, 1, 21, 37, False, True, False),    # split-bf16 1x1 (flat pixel run): nin_shortcut shape, batch 2, residual
+    (1, 256, 128, 1, 40, 50, False, False, False),   # split-bf16 1x1, one cout block
+    (1, 96, 64, 1, 17, 19, False, True, False),      # split-bf16 1x1, 64-cout block variant, 3 phases, ragged last pixel tile
+    (1, 512, 512, 1, 31, 33, False, True, False),    # proj_out shape (+ the queue's residual add)
 ]
 
 
