@@ -196,6 +196,11 @@ int mdtile_conv_pack(const float* d_w_oihw, float* d_w_packed, int cout, int cin
 int mdtile_conv2d(const float* d_x, const float* d_w_packed, const float* d_bias, const float* d_residual, float* d_y,
                   int B, int cin, int cout, int H, int W, int ksize, int flags, int out_layout, mdtile_stream_t stream);
 
+/* ldm Downsample (encoder 'downsample' task, tilevae.py:155-171): y = conv3x3_stride2(pad(x, right 1, bottom 1)) + bias,
+ * y is [B, cout, (Hin-2)/2+1, (Win-2)/2+1].  d_w_packed: mdtile_conv_pack(ksize 3) of the conv's OIHW weights. */
+int mdtile_conv2d_down2(const float* d_x, const float* d_w_packed, const float* d_bias, float* d_y, int B, int cin, int cout,
+                        int Hin, int Win, mdtile_stream_t stream);
+
 /* Fused pre-activation: the fixed-statistics GroupNorm + SiLU that precedes conv1 / conv2 of every ResnetBlock
  * (custom_group_norm + inplace_nonlinearity, tilevae.py:218-245, 102-104; queue order pre_norm, silu, conv1 ... :115-137)
  * is applied while the conv stages its input, so the normalised activation never makes a round trip through HBM.

@@ -33,10 +33,12 @@ struct ConvParams {
     int ptiles, PX, NCB;
 };
 
-template <int KS, int KC, int WP, int WC, int RP, int RC, bool TOKMAJ>
+// S = 2: ldm's Downsample (F.pad(x, (0,1,0,1)) then a stride-2 3x3 conv without padding; the encoder's 'downsample' task,
+// scripts/tilevae.py:155-171): out[y][x] = sum w[dy][dx] in[2y+dy][2x+dx], zero beyond the last input row / column.
+template <int KS, int KC, int WP, int WC, int RP, int RC, bool TOKMAJ, int S = 1>
 __global__ __launch_bounds__(256) void k_conv(const ConvParams P) {
     static_assert(WP * WC == 4 && WP * RP == 8, "4 waves cover 8 rows");
-    constexpr int PAD = KS / 2, ROWS = 8 + KS - 1, TWP = 32 + KS - 1, TAPS = KS * KS, BN = WC * RC * 32;
+    constexpr int PAD = S == 1 ? KS / 2 : 0, ROWS = 7 * S + KS, TWP = 31 * S + KS, TAPS = KS * KS, BN = WC * RC * 32;
     constexpr int E_IN = KC * ROWS * TWP, E_IN_P = (E_IN + 3) & ~3, E_WT = TAPS * KC * BN;
     constexpr int NI = (E_IN + 255) / 256, NW = (E_WT / 4 + 255) / 256, BUF = E_IN_P + E_WT;
     __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
@@ -63,8 +65,9 @@ __global__ __launch_bounds__(256) void k_conv(const ConvParams P) {
         if (idx < E_IN) {
             const int kc = idx / (ROWS * TWP), rem = idx - kc * (ROWS * TWP);
             const int r = rem / TWP, c = rem - r * TWP;
-            const int gy = y0 + r - PAD, gx = x0 + c - PAD;
-            if (gy >= 0 && gy < P.H && gx >= 0 && gx < P.W) {
+            const int gy = y0 * S + r - PAD, gx = x0 * S + c - PAD;
+            const int hlim = S == 1 ? P.H : P.Hin, wlim = S == 1 ? P.W : P.Win;   // S = 1: bounds of the (possibly upsampled) input view
+            if (gy >= 0 && gy < hlim && gx >= 0 && gx < wlim) {
                 const int sy = P.up ? gy >> 1 : gy, sx = P.up ? gx >> 1 : gx;
                 goff[i] = (kc << 24) | (sy * P.Win + sx);
             }
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(256) void k_conv(const ConvParams P) {
         const float* in_l = smem + (st & 1) * BUF;
         const float* wt_l = in_l + E_IN_P;
         // lane view: hi selects the k of the pair, l31 the pixel / the output channel
-        const float* inb = in_l + hi * (ROWS * TWP) + (wp * RP) * TWP + l31;
+        const float* inb = in_l + hi * (ROWS * TWP) + (wp * RP) * S * TWP + l31 * S;
         const float* wtb = wt_l + hi * BN + wc * (RC * 32) + l31;
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(256) void k_conv(const ConvParams P) {
 #pragma unroll
                 for (int j = 0; j < RC; ++j) wv[j] = wtb[(tap * KC + 2 * s) * BN + j * 32];
 #pragma unroll
-                for (int r = 0; r < RP; ++r) xv[r] = inb[(2 * s * ROWS + r + dy) * TWP + dx];
+                for (int r = 0; r < RP; ++r) xv[r] = inb[(2 * s * ROWS + r * S + dy) * TWP + dx];
 #pragma unroll
                 for (int r = 0; r < RP; ++r)
 #pragma unroll
@@ -203,6 +206,18 @@ int launch_conv(ConvParams& P, int out_layout, hipStream_t s) {
     dim3 grid(((P.ptiles + 7) / 8) * 8 * P.NCB, P.B), block(256);
     if (out_layout == 1) hipLaunchKernelGGL((k_conv<KS, KC, WP, WC, RP, RC, true>), grid, block, 0, s, P);
     else hipLaunchKernelGGL((k_conv<KS, KC, WP, WC, RP, RC, false>), grid, block, 0, s, P);
+    MDT_LAUNCH_CHECK();
+    return MDTILE_OK;
+}
+
+template <int KC, int WP, int WC, int RP, int RC>
+int launch_conv_down2(ConvParams& P, hipStream_t s) {
+    constexpr int BN = WC * RC * 32;
+    P.PX = (P.W + 31) / 32;
+    P.ptiles = P.PX * ((P.H + 7) / 8);
+    P.NCB = (P.CoutP + BN - 1) / BN;
+    dim3 grid(((P.ptiles + 7) / 8) * 8 * P.NCB, P.B), block(256);
+    hipLaunchKernelGGL((k_conv<3, KC, WP, WC, RP, RC, false, 2>), grid, block, 0, s, P);
     MDT_LAUNCH_CHECK();
     return MDTILE_OK;
 }
@@ -298,4 +313,23 @@ extern "C" int mdtile_conv2d_gn(const float* d_x, const float* d_coef, const flo
     MDT_CHECK_ARG((size_t)H * W < (1u << 24), "mdtile_conv2d_gn: input plane too large for the staging map");
     return conv_bf16x3_launch(d_x, d_w_packed + f32_packed_floats(cout, cin, ksize), d_bias, d_residual, d_y, B, cin, cout, H, W, 0, d_coef,
                               as_stream(stream));
+}
+
+// ldm Downsample: y = conv3x3_stride2(pad(x, right 1, bottom 1)); output (Hin - 2) / 2 + 1 rows (likewise columns).
+// Weights: the fp32 image of mdtile_conv_pack(ksize 3).  Exact-fp32 MFMA kernel (the three downsample convs are ~4 % of the
+// encoder's conv work).
+extern "C" int mdtile_conv2d_down2(const float* d_x, const float* d_w_packed, const float* d_bias, float* d_y, int B, int cin, int cout,
+                                   int Hin, int Win, mdtile_stream_t stream) {
+    MDT_CHECK_ARG(d_x && d_w_packed && d_y, "mdtile_conv2d_down2: null argument");
+    MDT_CHECK_ARG(B > 0 && B <= 65535 && cin > 0 && cout > 0 && Hin >= 2 && Win >= 2, "mdtile_conv2d_down2: bad shape B=%d cin=%d cout=%d Hin=%d Win=%d",
+                  B, cin, cout, Hin, Win);
+    MDT_CHECK_ARG((size_t)Hin * Win < (1u << 24), "mdtile_conv2d_down2: input plane too large for the staging map");
+    ConvParams P;
+    P.x = d_x; P.w = d_w_packed; P.bias = d_bias; P.res = nullptr; P.y = d_y;
+    P.B = B; P.Cin = cin; P.Cout = cout; P.CoutP = round_up(cout, 32);
+    P.H = (Hin - 2) / 2 + 1; P.W = (Win - 2) / 2 + 1;
+    P.Hin = Hin; P.Win = Win; P.up = 0;
+    hipStream_t s = as_stream(stream);
+    if (P.CoutP > 64) return launch_conv_down2<8, 2, 2, 4, 2>(P, s);
+    return launch_conv_down2<8, 4, 1, 2, 1>(P, s);
 }

@@ -78,6 +78,7 @@ _SIGNATURES = {
     "mdtile_conv_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mdtile_conv2d": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                               c_int, c_int, c_void_p]),
+    "mdtile_conv2d_down2": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mdtile_gn_sums": (c_int, [c_void_p, c_int, c_int, c_size_t, c_size_t, c_size_t, c_int, c_void_p, c_void_p, c_void_p]),
     "mdtile_gn_from_sums": (c_int, [c_void_p, ctypes.c_double, c_int, c_void_p, c_void_p, c_void_p]),
     "mdtile_vae_attn_qk_ws_size": (c_size_t, [c_int, c_int, c_int, c_int]),
@@ -481,6 +482,16 @@ class PackedConv:
         self.packed = torch.empty(n, dtype=torch.float32, device=weight.device)
         _check(lib().mdtile_conv_pack(_p(weight), _p(self.packed), self.cout, self.cin, self.ksize, _stream()), "mdtile_conv_pack")
         self.bias = None if bias is None else _dev_tensor(bias.detach().contiguous(), "bias", torch.float32)
+
+    def down2(self, x: torch.Tensor) -> torch.Tensor:
+        """ldm Downsample: conv3x3 stride 2 over pad(x, right 1, bottom 1) (encoder 'downsample' task)."""
+        _dev_tensor(x, "x", torch.float32)
+        B, cin, H, W = x.shape
+        assert cin == self.cin and self.ksize == 3 and H >= 2 and W >= 2
+        y = torch.empty((B, self.cout, (H - 2) // 2 + 1, (W - 2) // 2 + 1), dtype=torch.float32, device=x.device)
+        _check(lib().mdtile_conv2d_down2(_p(x), _p(self.packed), _p(self.bias), _p(y), B, self.cin, self.cout, H, W, _stream()),
+               "mdtile_conv2d_down2")
+        return y
 
     def fuses_pre_gn(self, upsample2x: bool = False, token_major: bool = False, exact: bool = False) -> bool:
         """True when this conv has a kernel that applies GroupNorm + SiLU to its input on load (mdtile_conv2d_gn)."""

@@ -12,7 +12,9 @@ What changed underneath (MI355X-first, 288 GB HBM):
     exists only to fit small VRAM);
   * GroupNorm semantics are upstream's: statistics frozen from a down-sampled latent in fast mode (:542-563, :464-505)
     or pooled across tiles at every norm in slow mode (:320-335) -- NOT the untiled network's.
-The encoder direction is not built yet: `encoder.forward` is left untouched.
+Both directions run on the engine: the decoder (latent -> image, pad 11) and the encoder (image -> latent moments, pad 32,
+stride-2 `Downsample` convs, optional `color_fix` semi-fast mode: statistics frozen only up to the first downsample,
+upstream :492-496).
 """
 from __future__ import annotations
 
@@ -53,11 +55,11 @@ def get_rcmd_dec_tsize() -> int:
 # program = upstream's task queue, with the fusions the engine offers already applied
 # ---------------------------------------------------------------------------------------------------------------------
 class Step:
-    __slots__ = ("kind", "conv", "norm", "silu", "attn", "fuse_res", "upsample")
+    __slots__ = ("kind", "conv", "norm", "silu", "attn", "fuse_res", "upsample", "downsample")
 
-    def __init__(self, kind, conv=None, norm=None, silu=False, attn=None, fuse_res=False, upsample=False):
+    def __init__(self, kind, conv=None, norm=None, silu=False, attn=None, fuse_res=False, upsample=False, downsample=False):
         self.kind, self.conv, self.norm, self.silu, self.attn = kind, conv, norm, silu, attn
-        self.fuse_res, self.upsample = fuse_res, upsample
+        self.fuse_res, self.upsample, self.downsample = fuse_res, upsample, downsample
 
 
 class AttnPack:
@@ -78,7 +80,11 @@ class AttnPack:
 
 
 def _pack(conv) -> mdtile.PackedConv:
-    assert conv.stride == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1, "engine convs are stride-1 dense"
+    if conv.stride == (2, 2):
+        # ldm Downsample.conv: 3x3, stride 2, no padding (the module pads right/bottom by one itself) -> PackedConv.down2
+        assert conv.kernel_size == (3, 3) and conv.padding == (0, 0) and conv.dilation == (1, 1) and conv.groups == 1, f"unsupported conv {conv}"
+        return mdtile.PackedConv(conv.weight.detach().float().contiguous(), None if conv.bias is None else conv.bias.detach().float())
+    assert conv.stride == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1, "engine convs are stride-1 (or ldm Downsample) dense"
     k = conv.kernel_size[0]
     assert conv.kernel_size == (k, k) and conv.padding == (k // 2, k // 2), f"unsupported conv {conv}"
     return mdtile.PackedConv(conv.weight.detach().float().contiguous(),
@@ -109,23 +115,34 @@ def build_task_queue(net, is_decoder: bool = True, pack=None) -> List[Step]:
     with num_res_blocks+1 resblocks (+ upsample except on level 0), norm_out, silu, conv_out.  30 norms for SD/SDXL.
     `pack` turns an nn.Conv2d into the callable a step carries (default: engine weights, mdtile.PackedConv; the CPU tests
     of the multi-GPU host logic inject their own)."""
-    if not is_decoder:
-        raise NotImplementedError("mdtile engine: the encoder direction is not built yet")
     pack = pack or _pack
     steps = [Step("conv", conv=pack(net.conv_in))]
-    _resblock(steps, net.mid.block_1, pack)
-    steps += [Step("store_res"), Step("norm", norm=_norm_params(net.mid.attn_1.norm)),
-              Step("attn", attn=AttnPack(net.mid.attn_1, pack))]
-    _resblock(steps, net.mid.block_2, pack)
-    for lvl in reversed(range(net.num_resolutions)):
-        for i in range(net.num_res_blocks + 1):
-            _resblock(steps, net.up[lvl].block[i], pack)
-        if lvl != 0:
-            steps.append(Step("conv", conv=pack(net.up[lvl].upsample.conv), upsample=True))  # nearest-2x fused
-    if not net.give_pre_end:
+
+    def _mid():
+        _resblock(steps, net.mid.block_1, pack)
+        steps.extend([Step("store_res"), Step("norm", norm=_norm_params(net.mid.attn_1.norm)),
+                      Step("attn", attn=AttnPack(net.mid.attn_1, pack))])
+        _resblock(steps, net.mid.block_2, pack)
+
+    if is_decoder:
+        _mid()
+        for lvl in reversed(range(net.num_resolutions)):
+            for i in range(net.num_res_blocks + 1):
+                _resblock(steps, net.up[lvl].block[i], pack)
+            if lvl != 0:
+                steps.append(Step("conv", conv=pack(net.up[lvl].upsample.conv), upsample=True))  # nearest-2x fused
+    else:
+        # encoder (upstream :155-171): levels bottom-up with num_res_blocks resblocks (+ downsample except on the last), then mid
+        for lvl in range(net.num_resolutions):
+            for i in range(net.num_res_blocks):
+                _resblock(steps, net.down[lvl].block[i], pack)
+            if lvl != net.num_resolutions - 1:
+                steps.append(Step("conv", conv=pack(net.down[lvl].downsample.conv), downsample=True))
+        _mid()
+    if not is_decoder or not net.give_pre_end:
         steps.append(Step("norm", norm=_norm_params(net.norm_out), silu=True))
         steps.append(Step("conv", conv=pack(net.conv_out)))
-        if net.tanh_out:
+        if is_decoder and net.tanh_out:
             steps.append(Step("tanh"))
     return steps
 
@@ -236,7 +253,10 @@ class VAEHook:
             if s.kind == "store_res":
                 st.res.append(st.x if s.conv is None else s.conv(st.x))
             elif s.kind == "conv":
-                st.x = s.conv(st.x, residual=st.res.pop() if s.fuse_res else None, upsample2x=s.upsample, pre_gn=st.pre)
+                if s.downsample:
+                    st.x = s.conv.down2(st.x)
+                else:
+                    st.x = s.conv(st.x, residual=st.res.pop() if s.fuse_res else None, upsample2x=s.upsample, pre_gn=st.pre)
                 st.pre = None
             elif s.kind == "attn":
                 st.x = s.attn(st.x, st.res.pop())
@@ -249,7 +269,8 @@ class VAEHook:
         s = steps[st.pc]
         gamma, beta = s.norm
         nxt = steps[st.pc + 1] if st.pc + 1 < len(steps) else None
-        if FUSE_PRE_GN and s.silu and nxt is not None and nxt.kind == "conv" and nxt.conv.fuses_pre_gn(upsample2x=nxt.upsample):
+        if (FUSE_PRE_GN and s.silu and nxt is not None and nxt.kind == "conv" and not nxt.downsample
+                and nxt.conv.fuses_pre_gn(upsample2x=nxt.upsample)):
             # norm + SiLU ride on the conv's input staging: only the per-channel (a, s) pair is formed here
             st.pre = mdtile.gn_coeffs(mean, var, gamma, beta, st.x.shape[1], 32, 1e-6)
         else:
@@ -264,6 +285,11 @@ class VAEHook:
         st = TileState(z)
         frozen = []
         n_norm = sum(1 for s in steps if s.kind == "norm")
+        if self.color_fix:
+            # semi-fast encoder mode (upstream :492-496): the estimate stops at the first downsample; only the norms before
+            # it are frozen, the others are pooled across the tiles as in slow mode
+            first_down = next((i for i, s in enumerate(steps) if s.kind == "conv" and s.downsample), len(steps))
+            n_norm = sum(1 for s in steps[:first_down] if s.kind == "norm")
         while True:
             self._run_until_norm(steps, st)
             if st.pc >= len(steps):
@@ -318,7 +344,7 @@ class VAEHook:
             zs = mdtile.vae_fast_input(z, self.tile_size)
             print(f"[Tiled VAE]: Fast mode enabled, estimating group norm parameters on {zs.shape[3]} x {zs.shape[2]} image")
             rank, world = self.shard
-            if world > 1 and SP_ESTIMATOR and zs.shape[2] >= 2 * world:
+            if world > 1 and SP_ESTIMATOR and self.is_decoder and zs.shape[2] >= 2 * world:
                 # the estimator is one untiled pass: split it by rows across the ranks instead of repeating it on each
                 from mdtile import seqpar
                 frozen = seqpar.estimate_group_norm_sp(steps, zs, seqpar.BandComm(rank, world), seqpar.EngineOps(), FUSE_PRE_GN)
@@ -335,12 +361,14 @@ class VAEHook:
             nonlocal result
             x = tiles[i].x
             if result is None:
-                result = torch.zeros((N, x.shape[1], height * 8, width * 8), device=dev, dtype=torch.float32)
+                oh, ow = (height * 8, width * 8) if self.is_decoder else (height // 8, width // 8)
+                result = torch.zeros((N, x.shape[1], oh, ow), device=dev, dtype=torch.float32)
             devices.test_for_nans(x, "vae")
             mdtile.crop_store(x, in_bboxes[i], out_bboxes[i], result, self.is_decoder)
             tiles[i] = None
 
-        if frozen is not None:
+        n_norm_total = sum(1 for s in steps if s.kind == "norm")
+        if frozen is not None and len(frozen) == n_norm_total:
             # every norm is already resolved: each tile runs start to finish on its own (upstream: one sweep)
             for i in mine:
                 if state.interrupted:
@@ -356,19 +384,30 @@ class VAEHook:
                 finish(i)
         else:
             # slow mode: all tiles advance in lockstep from norm to norm; statistics pooled over tiles at each one
+            # (semi-fast: the first len(frozen) norms use the frozen statistics instead of the pool)
             forward = True
+            k_norm = 0
             while not interrupted:
+                use_frozen = frozen is not None and k_norm < len(frozen)
                 gp = GroupNormParam()
                 for i in (mine if forward else reversed(mine)):
                     if state.interrupted:
                         interrupted = True
                         break
                     self._run_until_norm(steps, tiles[i])
-                    if tiles[i].pc < len(steps):
+                    if tiles[i].pc < len(steps) and not use_frozen:
                         gp.add_tile(tiles[i].x)
                 if interrupted:
                     break
+                if use_frozen:
+                    # a frozen norm is no barrier upstream (the tile runs straight through it): no pooling, no collective,
+                    # no change of the zig-zag direction.  A later pooled norm always exists in this branch.
+                    for i in mine:
+                        self._apply_norm(steps, tiles[i], *frozen[k_norm])
+                    k_norm += 1
+                    continue
                 pooled = gp.summary() if world == 1 else self._pooled_across_ranks(gp, steps, z.device)
+                k_norm += 1
                 if pooled is None:
                     for i in mine:
                         finish(i)
@@ -423,9 +462,11 @@ class Script(scripts.Script):
         vae = p.sd_model.first_stage_model
         decoder = vae.decoder
         if not enabled:
-            if self.hooked and isinstance(decoder.forward, VAEHook):
-                decoder.forward.net = None
-                decoder.forward = decoder.original_forward
+            if self.hooked:
+                for net in (decoder, getattr(vae, "encoder", None)):
+                    if net is not None and isinstance(net.forward, VAEHook):
+                        net.forward.net = None
+                        net.forward = net.original_forward
             self.hooked = False
             return
         if not hasattr(decoder, "original_forward"):
@@ -433,12 +474,17 @@ class Script(scripts.Script):
         self.hooked = True
         decoder.forward = VAEHook(decoder, decoder_tile_size, is_decoder=True, fast_decoder=fast_decoder,
                                   fast_encoder=fast_encoder, color_fix=color_fix, to_gpu=vae_to_gpu)
-        # encoder.forward is intentionally left alone until the encode direction lands in the engine
+        encoder = vae.encoder
+        if not hasattr(encoder, "original_forward"):
+            encoder.original_forward = encoder.forward
+        encoder.forward = VAEHook(encoder, encoder_tile_size, is_decoder=False, fast_decoder=fast_decoder,
+                                  fast_encoder=fast_encoder, color_fix=color_fix, to_gpu=vae_to_gpu)
 
     def postprocess(self, p, processed, enabled: bool, *args):
         if not enabled:
             return
-        decoder = p.sd_model.first_stage_model.decoder
-        if isinstance(decoder.forward, VAEHook):
-            decoder.forward.net = None
-            decoder.forward = decoder.original_forward
+        vae = p.sd_model.first_stage_model
+        for net in (vae.decoder, getattr(vae, "encoder", None)):
+            if net is not None and isinstance(net.forward, VAEHook):
+                net.forward.net = None
+                net.forward = net.original_forward

@@ -150,12 +150,13 @@ def build_ops(net, is_decoder: bool = True) -> list:
     return ops
 
 
-def _run_segment(ops, start: int, tile: torch.Tensor, res_stack: list, norm_fn: Callable):
-    """Run ops[start:] on one tile until the next 'norm' (exclusive) or the end.  Returns (tile, next_index)."""
+def _run_segment(ops, start: int, tile: torch.Tensor, res_stack: list, norm_fn: Callable, stop_at_resample: bool = False):
+    """Run ops[start:] on one tile until the next 'norm' (exclusive) or the end.  Returns (tile, next_index).
+    stop_at_resample: also stop (index of the op, not executed) at the first 'resample' -- the encoder's color_fix estimate."""
     i = start
     while i < len(ops):
         kind, mod = ops[i]
-        if kind == "norm":
+        if kind == "norm" or (stop_at_resample and kind == "resample"):
             return tile, i
         if kind == "store_res":
             res_stack.append(tile if mod is None else mod(tile))
@@ -185,13 +186,14 @@ def fast_mode_input(z: torch.Tensor, tile_size: int) -> torch.Tensor:
     return torch.clamp(d, min=z.min(), max=z.max())
 
 
-def estimate_stats(ops, z_small: torch.Tensor) -> List[Tuple[torch.Tensor, torch.Tensor]]:
-    """tilevae.py:464-505 -- run the whole op list on the small latent, freezing (var, mean) at every norm."""
+def estimate_stats(ops, z_small: torch.Tensor, color_fix: bool = False) -> List[Tuple[torch.Tensor, torch.Tensor]]:
+    """tilevae.py:464-505 -- run the whole op list on the small latent, freezing (var, mean) at every norm.
+    color_fix (encoder only, :492-496): the estimate returns at the first downsample; only the norms before it are frozen."""
     stats, res, tile, i = [], [], z_small, 0
     n_norm = sum(1 for k, _ in ops if k == "norm")
     while True:
-        tile, i = _run_segment(ops, i, tile, res, None)
-        if i >= len(ops):
+        tile, i = _run_segment(ops, i, tile, res, None, stop_at_resample=color_fix)
+        if i >= len(ops) or ops[i][0] == "resample":
             break
         var, mean = get_var_mean(tile, 32)
         stats.append((var, mean))
@@ -204,7 +206,7 @@ def estimate_stats(ops, z_small: torch.Tensor) -> List[Tuple[torch.Tensor, torch
 
 
 @torch.no_grad()
-def tiled_forward(net, z: torch.Tensor, tile_size: int, fast: bool, is_decoder: bool = True) -> torch.Tensor:
+def tiled_forward(net, z: torch.Tensor, tile_size: int, fast: bool, is_decoder: bool = True, color_fix: bool = False) -> torch.Tensor:
     """tilevae.py:375-388 + 507-656.  Returns fp32 [N, C_out, 8H, 8W] (decoder)."""
     pad = DEC_PAD if is_decoder else ENC_PAD
     N, _, H, W = z.shape
@@ -213,7 +215,7 @@ def tiled_forward(net, z: torch.Tensor, tile_size: int, fast: bool, is_decoder: 
     ins, outs = split_tiles(H, W, tile_size, is_decoder)
     tiles = [z[:, :, b[2]:b[3], b[0]:b[1]].clone() for b in ins]
     ops = build_ops(net, is_decoder)
-    frozen = estimate_stats(ops, fast_mode_input(z, tile_size)) if fast else None
+    frozen = estimate_stats(ops, fast_mode_input(z, tile_size), color_fix and not is_decoder) if fast else None
     T = len(tiles)
     pos = [0] * T
     res = [[] for _ in range(T)]
@@ -231,7 +233,8 @@ def tiled_forward(net, z: torch.Tensor, tile_size: int, fast: bool, is_decoder: 
                 pixels.append(tiles[t].shape[2] * tiles[t].shape[3])
         if pos[0] >= len(ops):
             break
-        if frozen is not None:
+        is_frozen = frozen is not None and norm_idx < len(frozen)
+        if is_frozen:
             var, mean = frozen[norm_idx]
         else:
             var, mean = pool_stats(vars_, means, pixels)
@@ -240,7 +243,8 @@ def tiled_forward(net, z: torch.Tensor, tile_size: int, fast: bool, is_decoder: 
             tiles[t] = custom_group_norm(tiles[t], 32, mean, var, gn.weight, gn.bias)
             pos[t] += 1
         norm_idx += 1
-        forward = not forward
+        if not is_frozen:                # a frozen norm is an inline task upstream: the sweep (and its direction) goes on
+            forward = not forward
     for t in range(T):
         tile = tiles[t]
         if result is None:                                                  # tilevae.py:629-632

@@ -81,6 +81,26 @@ def test_tiled_decode_bit_exact(ref, H, W, ts, fast):
     assert torch.equal(hook(z), vo.tiled_forward(dec, z, ts, fast))
 
 
+@pytest.mark.parametrize("H,W,ts,fast,color_fix", [(160, 192, 64, True, False), (160, 192, 64, False, False),
+                                                   (136, 200, 64, True, True), (200, 120, 96, True, False)])
+def test_tiled_encode_bit_exact(ref, H, W, ts, fast, color_fix):
+    """Encoder direction (pad 32, stride-2 Downsample, color_fix semi-fast mode) -- upstream tilevae.py:155-171, 492-496."""
+    enc = ld.make_encoder(0, small=True)
+    enc.original_forward = enc.forward
+    torch.manual_seed(4)
+    x = torch.randn(1, 3, H, W)
+    hook = ref.tilevae.VAEHook(enc, ts, is_decoder=False, fast_decoder=False, fast_encoder=fast, color_fix=color_fix)
+    assert torch.equal(hook(x), vo.tiled_forward(enc, x, ts, fast, is_decoder=False, color_fix=color_fix))
+
+
+def test_encoder_task_queue_shape(ref):
+    enc = ld.make_encoder(0, small=True)
+    q = ref.tilevae.build_task_queue(enc, False)
+    ops = vo.build_ops(enc, False)
+    assert len(q) == len(ops)
+    assert sum(1 for t in q if t[0] == "pre_norm") == sum(1 for k, _ in ops if k == "norm")
+
+
 def test_gn_and_attn_primitives(ref):
     torch.manual_seed(11)
     t = torch.randn(2, 64, 9, 13) * 3 + 0.5
