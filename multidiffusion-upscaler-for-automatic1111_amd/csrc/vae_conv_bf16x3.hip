@@ -63,8 +63,13 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo
 // inplace_nonlinearity, scripts/tilevae.py:218-245, 102-104) is applied to the input while it is staged:
 // x' = silu(fma(x, a[c], s[c])) with a = gamma * rstd, s = beta - mean * a (mdtile_gn_coeffs) -- the normalised activation is
 // never written to HBM (1R + 1W of every pre-conv activation saved).  Zero padding applies to x' (mask after the transform).
-template <int MT, int TH_, bool GNS>  // MT: 32-cout tiles per block, 4 (BM = 128) or 2 (BM = 64); TH_: pixel rows per block, 8 or 16
-__global__ __launch_bounds__(512) void k_conv3x3_bf16x3(const ConvBParams P) {
+// WDMA = true: the weight chunks (already in fragment order) go global -> LDS by DMA (global_load_lds_dwordx4) instead of
+// through VGPRs + ds_write_b128; same two-stage schedule (issued at the start of a phase, drained before its closing barrier).
+// IB1 = true: ONE input stage instead of two (an extra barrier before the stage is overwritten, once per K-step) and a
+// 128-VGPR budget: 70.8 KB LDS + 128 registers let TWO blocks share a CU (4 waves per SIMD) -- the barrier / LDS-latency
+// stalls of one block are covered by the other block's MFMAs.  Only with MT = 4, TH_ = 8, WDMA.
+template <int MT, int TH_, bool GNS, bool WDMA, bool IB1 = false>  // MT: 32-cout tiles per block, 4 (BM = 128) or 2 (BM = 64); TH_: pixel rows per block, 8 or 16
+__global__ __launch_bounds__(512, IB1 ? 4 : 2) void k_conv3x3_bf16x3(const ConvBParams P) {
     constexpr int BM = MT * 32;
     constexpr int WAVES_M = MT / 2, WAVES_R = 8 / WAVES_M, NROW = TH_ / WAVES_R;
     constexpr int ROWS_ = TH_ + 2, IN_REC_ = 2 * ROWS_ * COLS;   // halo tile records per hl per stage
@@ -72,11 +77,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16x3(const ConvBParams P) {
     constexpr int W_REC = 2 * 3 * MT * 64;              // records per weight chunk (hi block then lo block)
     constexpr int NWREG = (W_REC + 511) / 512;          // 3 (MT = 4) or 2 (MT = 2, half of the threads on the 2nd)
     // LDS (16-byte records): input [2 stages][hl][IN_REC_], weights [2 stages][W_REC]
-    constexpr int IN_STAGE = 2 * IN_REC_;
-    __shared__ u32x4 smem[2 * IN_STAGE + 2 * W_REC];
+    constexpr int IN_STAGE = 2 * IN_REC_, NIST = IB1 ? 1 : 2;
+    __shared__ u32x4 smem[NIST * IN_STAGE + 2 * W_REC];
     __shared__ float4 coef_l[GNS ? 2 * MAX_GN_CIN / 4 : 1];   // a[0..Cin) at 0, s[0..Cin) at MAX_GN_CIN
     u32x4* const in_l = smem;
-    u32x4* const w_l = smem + 2 * IN_STAGE;
+    u32x4* const w_l = smem + NIST * IN_STAGE;
 
     // ---- block -> (pixel tile, cout block): XCD = id % 8 keeps all cout blocks of a pixel tile on one L2
     const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16x3(const ConvBParams P) {
         smask[i] = inside ? 1.0f : 0.0f;
     }
     float rin[NPASS][8];
-    u32x4 rwt[NWREG];
+    u32x4 rwt[WDMA ? 1 : NWREG];
 
     auto load_input = [&](int k) {       // K-step k: channels 16k .. 16k+15
 #pragma unroll
@@ -162,17 +167,27 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16x3(const ConvBParams P) {
         }
     };
     const u32x4* wsrc = P.w + (size_t)cb * P.NK * 3 * W_REC;
-    auto load_weights = [&](int ph) {    // phase ph = k*3 + dy: one contiguous chunk of W_REC records
+    auto load_weights = [&](int ph) {    // phase ph = k*3 + dy: one contiguous chunk of W_REC records (-> LDS stage ph & 1)
         const u32x4* src = wsrc + (size_t)ph * W_REC;
 #pragma unroll
         for (int i = 0; i < NWREG; ++i)
-            if (wave_u * 64 + 512 * i < W_REC) rwt[i] = src[tid + 512 * i];   // W_REC is a multiple of 64: whole waves
+            if (wave_u * 64 + 512 * i < W_REC) {   // W_REC is a multiple of 64: whole waves
+                if (WDMA)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + tid + 512 * i),
+                                                     (__attribute__((address_space(3))) void*)(w_l + (ph & 1) * W_REC + wave_u * 64 + 512 * i), 16, 0, 0);
+                else
+                    rwt[WDMA ? 0 : i] = src[tid + 512 * i];
+            }
     };
     auto store_weights = [&](int stage) {
+        if (WDMA) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's part of the chunk has landed (the barrier covers the others)
+            return;
+        }
         u32x4* dst = w_l + stage * W_REC;
 #pragma unroll
         for (int i = 0; i < NWREG; ++i)
-            if (wave_u * 64 + 512 * i < W_REC) dst[tid + 512 * i] = rwt[i];
+            if (wave_u * 64 + 512 * i < W_REC) dst[tid + 512 * i] = rwt[WDMA ? 0 : i];
     };
 
     f32x16 acc[2][NROW];
@@ -196,7 +211,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16x3(const ConvBParams P) {
         if (ph + 1 < nph) load_weights(ph + 1);
 
         const u32x4* wst = w_l + (ph & 1) * W_REC;
-        const u32x4* ist = in_l + (k & 1) * IN_STAGE;
+        const u32x4* ist = in_l + (IB1 ? 0 : (k & 1)) * IN_STAGE;
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
             bf16x8 a[2][2];   // [m][hl]
@@ -220,7 +235,10 @@ __global__ __launch_bounds__(512) void k_conv3x3_bf16x3(const ConvBParams P) {
         }
 
         if (ph + 1 < nph) store_weights((ph + 1) & 1);
-        if (dy == 2 && k + 1 < P.NK) store_input((k + 1) & 1, k + 1);
+        if (dy == 2 && k + 1 < P.NK) {
+            if (IB1) __syncthreads();      // single input stage: every wave must be done reading K-step k before it is overwritten
+            store_input(IB1 ? 0 : ((k + 1) & 1), k + 1);
+        }
         __syncthreads();
     }
 
@@ -528,7 +546,12 @@ namespace mdt {
 
 // shapes the split-bf16 3x3 kernel takes; everything else stays on the exact-fp32 kernel
 bool conv_bf16x3_eligible(int cout, int cin, int ksize) { return ksize == 3 && cin % 16 == 0 && cout >= 32; }
-static int conv_bf16x3_mt(int cout) { return cout > 64 ? 4 : 2; }
+// cout tiles per block: 128-cout blocks (1 block / CU) for wide convs; MDTILE_CONV_MT=2 forces 64-cout blocks (2 blocks / CU:
+// 4 waves per SIMD, each block's barrier stalls overlap the other's MFMAs) -- affects packing AND launch, set before first use
+static int conv_bf16x3_mt(int cout) {
+    static const int forced = [] { const char* e = getenv("MDTILE_CONV_MT"); return e ? atoi(e) : 0; }();
+    return (forced == 2 || cout <= 64) ? 2 : 4;
+}
 
 // record image = [ direct 3x3 records (9 taps) | sub-pixel upsample records (4 parities x 4 merged taps) ]
 static size_t direct_records(int cout, int cin) {
@@ -589,15 +612,33 @@ int conv_bf16x3_launch(const float* d_x, const void* d_w_rec, const float* d_bia
     P.NCB = round_up_i(cout, MT * 32) / (MT * 32);
     P.NK = cin / 16;
     dim3 grid(((P.ptiles + 7) / 8) * 8 * P.NCB, B), block(512);
-    if (d_coef) {
-        if (MT == 4 && th == 16) hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 16, true>), grid, block, 0, s, P);
-        else if (MT == 4) hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 8, true>), grid, block, 0, s, P);
-        else hipLaunchKernelGGL((k_conv3x3_bf16x3<2, 8, true>), grid, block, 0, s, P);
-    } else {
-        if (MT == 4 && th == 16) hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 16, false>), grid, block, 0, s, P);
-        else if (MT == 4) hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 8, false>), grid, block, 0, s, P);
-        else hipLaunchKernelGGL((k_conv3x3_bf16x3<2, 8, false>), grid, block, 0, s, P);
+    static const bool wdma = [] { const char* e = getenv("MDTILE_CONV_WDMA"); return e && strcmp(e, "1") == 0; }();
+    // MDTILE_CONV_OCC2=1: 128-cout x 8-row blocks with one input stage, two blocks per CU (weight DMA implied)
+    static const bool occ2 = [] { const char* e = getenv("MDTILE_CONV_OCC2"); return e && strcmp(e, "1") == 0; }();
+    if (occ2 && MT == 4) {
+        P.ptiles = P.PX * ((H + TH - 1) / TH);
+        dim3 grid2(((P.ptiles + 7) / 8) * 8 * P.NCB, B);
+        if (d_coef) hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 8, true, true, true>), grid2, block, 0, s, P);
+        else hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 8, false, true, true>), grid2, block, 0, s, P);
+        MDT_LAUNCH_CHECK();
+        return MDTILE_OK;
     }
+#define MDT_CONV_LAUNCH(MM, TT, GG, WW) hipLaunchKernelGGL((k_conv3x3_bf16x3<MM, TT, GG, WW>), grid, block, 0, s, P)
+#define MDT_CONV_PICK(GG, WW)                                  \
+    do {                                                       \
+        if (MT == 4 && th == 16) MDT_CONV_LAUNCH(4, 16, GG, WW); \
+        else if (MT == 4) MDT_CONV_LAUNCH(4, 8, GG, WW);       \
+        else MDT_CONV_LAUNCH(2, 8, GG, WW);                    \
+    } while (0)
+    if (d_coef) {
+        if (wdma) MDT_CONV_PICK(true, true);
+        else MDT_CONV_PICK(true, false);
+    } else {
+        if (wdma) MDT_CONV_PICK(false, true);
+        else MDT_CONV_PICK(false, false);
+    }
+#undef MDT_CONV_PICK
+#undef MDT_CONV_LAUNCH
     MDT_LAUNCH_CHECK();
     return MDTILE_OK;
 }

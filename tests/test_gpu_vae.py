@@ -285,3 +285,56 @@ def test_untiled_small_input_takes_original_forward(plugin, cuda):
     assert calls == [(1, 4, 48, 48)], "tiny inputs must be handed to the untouched original forward"
     # the host's own (MIOpen) convs are not run-to-run bit-stable on this stack: compare with a tolerance
     assert torch.allclose(out, inner(z), rtol=1e-4, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# encoder direction: stride-2 Downsample conv, encoder queue, pad 32, color_fix semi-fast mode
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,cin,cout,H,W", [(1, 128, 128, 40, 66), (2, 32, 32, 17, 21), (1, 256, 256, 64, 64), (1, 512, 512, 33, 95)])
+def test_downsample_conv_vs_torch(plugin, cuda, B, cin, cout, H, W):
+    """ldm Downsample: F.pad(x, (0,1,0,1)) then conv3x3 stride 2 (odd and even sizes)."""
+    E = plugin.engine
+    torch.manual_seed(cin + H)
+    conv = torch.nn.Conv2d(cin, cout, 3, 2, 0)
+    x = torch.randn(B, cin, H, W)
+    with torch.no_grad():
+        ref = conv(F.pad(x, (0, 1, 0, 1)))
+    pc = E.PackedConv(conv.weight.detach().to(cuda), conv.bias.detach().to(cuda))
+    out = pc.down2(x.to(cuda)).cpu()
+    assert out.shape == ref.shape
+    assert _rel(out, ref) < 2e-5
+
+
+def test_tiled_encode_vs_goldens_and_oracle(plugin, cuda):
+    import json, os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    with open(os.path.join(here, "cases_enc.json")) as f:
+        enc_cases = json.load(f)["enc"]
+    gold = np.load(os.path.join(here, "vae_enc.npz"))
+    for c in enc_cases:
+        enc = ld.make_encoder(c["enc_seed"], small=True).to(cuda)
+        enc.original_forward = enc.forward
+        torch.manual_seed(c["seed"])
+        x = torch.randn(1, 3, c["H"], c["W"])
+        hook = plugin.tilevae.VAEHook(enc, c["ts"], is_decoder=False, fast_decoder=False, fast_encoder=c["fast"], color_fix=c["color_fix"])
+        out = hook(x.to(cuda)).cpu()
+        g = torch.from_numpy(gold[c["name"] + "/out"])
+        assert out.shape == g.shape, f"{c['name']}: shape {tuple(out.shape)} vs upstream {tuple(g.shape)}"
+        err = _rel(out, g)
+        assert err < 1e-3, f"{c['name']}: rel err vs the upstream golden {err}"
+
+
+@pytest.mark.parametrize("fast,color_fix", [(True, False), (False, False), (True, True)])
+def test_tiled_encode_full_width_encoder(plugin, cuda, fast, color_fix):
+    """The real SD/SDXL encoder widths (ch=128 ... 512, attention at C=512) on a small image, against the oracle."""
+    enc_cpu = ld.make_encoder(2)
+    torch.manual_seed(6)
+    x = torch.randn(1, 3, 168, 136)
+    ref = vo.tiled_forward(enc_cpu, x, 64, fast, is_decoder=False, color_fix=color_fix)
+    enc = ld.make_encoder(2).to(cuda)
+    enc.original_forward = enc.forward
+    hook = plugin.tilevae.VAEHook(enc, 64, is_decoder=False, fast_decoder=False, fast_encoder=fast, color_fix=color_fix)
+    out = hook(x.to(cuda)).cpu()
+    assert out.shape == ref.shape
+    err = _rel(out, ref)
+    assert err < 1e-3, f"full-width tiled encode (fast={fast}, color_fix={color_fix}): rel err {err}"

@@ -65,6 +65,21 @@ def test_vae(cases, golden_vae):
         assert np.array_equal(mom, golden_vae[c["name"] + "/moments"]), c["name"]
 
 
+def test_vae_encoder_goldens():
+    """Encoder direction (pad 32, Downsample, color_fix): the oracle reproduces the upstream-generated vectors bit for bit."""
+    import json, os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    with open(os.path.join(here, "cases_enc.json")) as f:
+        enc_cases = json.load(f)["enc"]
+    gold = np.load(os.path.join(here, "vae_enc.npz"))
+    for c in enc_cases:
+        enc = ld.make_encoder(c["enc_seed"], small=True)
+        torch.manual_seed(c["seed"])
+        x = torch.randn(1, 3, c["H"], c["W"])
+        out = vo.tiled_forward(enc, x, c["ts"], c["fast"], is_decoder=False, color_fix=c["color_fix"])
+        assert np.array_equal(out.numpy(), gold[c["name"] + "/out"]), c["name"]
+
+
 def test_gn_attn(golden_vae):
     torch.manual_seed(11)
     t = torch.randn(2, 64, 9, 13) * 3 + 0.5
