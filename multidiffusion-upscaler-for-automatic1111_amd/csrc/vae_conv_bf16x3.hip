@@ -613,8 +613,10 @@ int conv_bf16x3_launch(const float* d_x, const void* d_w_rec, const float* d_bia
     P.NK = cin / 16;
     dim3 grid(((P.ptiles + 7) / 8) * 8 * P.NCB, B), block(512);
     static const bool wdma = [] { const char* e = getenv("MDTILE_CONV_WDMA"); return e && strcmp(e, "1") == 0; }();
-    // MDTILE_CONV_OCC2=1: 128-cout x 8-row blocks with one input stage, two blocks per CU (weight DMA implied)
-    static const bool occ2 = [] { const char* e = getenv("MDTILE_CONV_OCC2"); return e && strcmp(e, "1") == 0; }();
+    // default for the 128-cout blocks: 8-row blocks with ONE input stage + weight DMA, two blocks per CU (4 waves / SIMD) --
+    // measured +3..11 % over the 16-row one-block-per-CU variant on the decoder's shapes (profiles/r1g/conv_probe_r1g.log);
+    // MDTILE_CONV_OCC2=0 selects the 16-row variant (MDTILE_CONV_TH / MDTILE_CONV_WDMA then apply)
+    static const bool occ2 = [] { const char* e = getenv("MDTILE_CONV_OCC2"); return !(e && strcmp(e, "0") == 0); }();
     if (occ2 && MT == 4) {
         P.ptiles = P.PX * ((H + TH - 1) / TH);
         dim3 grid2(((P.ptiles + 7) / 8) * 8 * P.NCB, B);
