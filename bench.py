@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the per-stage split and the HIP-event roofline pass (PMC runs)")
     ap.add_argument("--cpu-vae-latent", type=int, default=88, help="width of the 64-row latent of the CPU VAE sample")
+    ap.add_argument("--debug-single-device", action="store_true",
+                    help="functional check of the N > 1 flow on ONE GPU: every rank uses cuda:0 and gloo (host-staged) instead "
+                         "of RCCL; the numbers it prints are meaningless")
     return ap.parse_args()
 
 
@@ -94,12 +97,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback path exists in the product)")
+    if args.debug_single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.debug_single_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import __graft_entry__ as ge
     if rank == 0:
@@ -205,15 +213,17 @@ def main():
     finally:
         builtins.print = _print
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if args.debug_single_device else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     ms_per_step = elapsed / args.steps * 1e3
     value = L * L / (elapsed / args.steps)
 
     # ------------------------------------------------------------------ per-kernel roofline (instrumented extra pass)
+    # (every rank runs it: with N > 1 the decode contains collectives -- sequence-parallel estimator -- that all ranks must enter;
+    # only rank 0's figures are reported)
     roofline = roofline_blend = None
-    if rank == 0 and not args.no_profile_pass:
+    if not args.no_profile_pass:
         prof = Profile()
         s_bytes = 4
         T_local = plan.num_tiles if world == 1 else n_local
@@ -277,6 +287,20 @@ def main():
                         "breakdown_tflops": {k: round(v[1] / v[2] / 1e12, 2) for k, v in sorted(conv_tags.items())}}
         elif roofline_blend is not None:
             roofline = roofline_blend
+
+    # HBM traffic per launch from a PREVIOUS pair of rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
+    # (tools/pmc_summary.py writes the json; the counters cannot be read from inside the process)
+    pmc_path = os.environ.get("MDTILE_PMC_SUMMARY", "")
+    if rank == 0 and pmc_path and os.path.exists(pmc_path):
+        with open(pmc_path) as f:
+            pmc = json.load(f)
+        for rl, needle in ((roofline, {"conv3x3_wide": "k_conv3x3_bf16x3", "attn": "k_attn_bf16x3", "upconv_subpixel": "k_upconv_bf16x3"}.get(
+                (roofline or {}).get("kernel", ""), "")), (roofline_blend, "k_blend")):
+            if rl is not None and needle:
+                hit = [v for k, v in pmc.get("kernels", {}).items() if needle in k]
+                if hit:
+                    rl["traffic"] = int(sum(h["hbm_bytes_per_launch"] * h["dispatches"] for h in hit) / max(1, sum(h["dispatches"] for h in hit)))
+                    rl["traffic_unit"] = "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
 
     # ------------------------------------------------------------------ CPU baseline (oracle = port of the reference), rank 0, N=1
     cpu_baseline = None

@@ -12,9 +12,10 @@ Blend (one model evaluation):
     sums), and finalises its rows (mdtile_blend_finalize).  Every rank ends up with the finished rows its own tiles need for
     the next evaluation -- no second exchange, no full-canvas collective.
 
-VAE decode: tiles are dealt round-robin; fast-mode statistics are estimated redundantly from the same down-sampled latent
-    (bit-identical on every rank, no communication); slow mode all-reduces 2*B*32+1 floats per GroupNorm barrier.
-    Output tiles are disjoint; they stay sharded unless the caller gathers them.
+VAE decode: tiles are dealt round-robin; the fast-mode statistics estimator (one untiled pass) is split by rows across the
+    ranks (mdtile/seqpar.py; MDTILE_SP_ESTIMATOR=0: every rank repeats it, bit-identical, no communication); slow mode
+    all-reduces 2*B*32+1 floats per GroupNorm barrier.  Output tiles are disjoint; they stay sharded unless the caller
+    gathers them.
 """
 from __future__ import annotations
 
@@ -88,7 +89,12 @@ def exchange_and_sum(partial: torch.Tensor, bands: Sequence[Band], rank: int, gr
     halos = halo_rows(bands, rank)
     if not halos:
         return partial
+    # RCCL ("nccl") moves device memory directly; a backend that cannot (gloo: CPU tests, single-GPU multi-process checks)
+    # gets the slabs staged through the host
+    staged = partial.is_cuda and dist.get_backend(group) == "gloo"
     send = {peer: partial[:, :, lo:hi, :].contiguous() for peer, lo, hi in halos}
+    if staged:
+        send = {peer: t.cpu() for peer, t in send.items()}
     recv = {peer: torch.empty_like(send[peer]) for peer, _, _ in halos}
     ops = []
     for peer, _, _ in halos:
@@ -96,6 +102,9 @@ def exchange_and_sum(partial: torch.Tensor, bands: Sequence[Band], rank: int, gr
         ops.append(dist.P2POp(dist.irecv, recv[peer], peer, group=group))
     for req in dist.batch_isend_irecv(ops):
         req.wait()
+    if staged:
+        send = {peer: t.to(partial.device) for peer, t in send.items()}
+        recv = {peer: t.to(partial.device) for peer, t in recv.items()}
     # deterministic, rank-symmetric summation order: contributions are added in ascending rank order on BOTH sides.
     # rows can be shared by more than two bands, so build each shared row range from all contributors.
     events = sorted(set([r for _, lo, hi in halos for r in (lo, hi)]))
