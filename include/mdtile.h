@@ -154,6 +154,13 @@ int mdtile_blend(const mdtile_plan* plan, const mdtile_blend_args* args, const v
 int mdtile_blend_finalize(const mdtile_plan* plan, const mdtile_blend_args* args, const float* d_partial,
                           const mdtile_region* regions, int num_regions, mdtile_stream_t stream);
 
+/* Per-region initial noise (scripts/tilediffusion.py:486-529, create_random_tensors_hijack): d_noise [N,C,H,W] fp32 is the job's
+ * noise, updated in place.  regions[i].out = the region's own noise [1,C,h,w] fp32 (drawn by the host with the region's CPU
+ * seed, shared by all N samples), .mode = MDTILE_REGION_BG / _FG, .weight unused.  Per layer: sum + hit count over the regions
+ * in list order, averaged where count > 1; background layer pasted where its count > 0, foreground layer on top.  <= 16 regions. */
+int mdtile_region_noise(float* d_noise, int N, int C, int H, int W, const mdtile_region* regions, int num_regions,
+                        mdtile_stream_t stream);
+
 /* ----------------------------------------------------------------------------------------------------------
  * Tiled VAE (scripts/tilevae.py).  All tensors fp32 NCHW.
  * -------------------------------------------------------------------------------------------------------- */

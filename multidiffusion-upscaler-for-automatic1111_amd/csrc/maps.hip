@@ -134,3 +134,58 @@ extern "C" int mdtile_rect_mul_canvas(float* d_rect_w, const float* d_canvas, in
     MDT_LAUNCH_CHECK();
     return MDTILE_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Per-region initial noise (scripts/tilediffusion.py:486-529, create_random_tensors_hijack): every enabled region draws its
+// own CPU-seeded noise [1, C, h, w]; background and foreground regions are summed into two layers with hit counts, each layer
+// is averaged where more than one region covers a pixel, and pasted over the job's noise -- background first, foreground on
+// top.  Gather-formulated like the blend: one thread owns one element of the output, walks the regions in upstream's order
+// (fp32 sums in the same order as the sequential `+=`, counts are exact small integers) -> bit-identical to upstream.
+namespace {
+constexpr int MAX_NOISE_REGIONS = 16;   // upstream caps the UI at 16 regions (BBOX_MAX_NUM)
+struct NoiseRegions {
+    int x[MAX_NOISE_REGIONS], y[MAX_NOISE_REGIONS], w[MAX_NOISE_REGIONS], h[MAX_NOISE_REGIONS], mode[MAX_NOISE_REGIONS];
+    const float* rand[MAX_NOISE_REGIONS];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void k_region_noise(float* __restrict__ noise, int C, int H, int W, const NoiseRegions R) {
+    const int px = blockIdx.x * 256 + threadIdx.x;
+    if (px >= H * W) return;
+    const int plane = blockIdx.y, c = plane % C;     // plane = n*C + c; the region noise is shared by every sample n
+    const int y = px / W, x = px - y * W;
+    float bg = 0.0f, bgc = 0.0f, fg = 0.0f, fgc = 0.0f;
+    for (int r = 0; r < R.n; ++r) {
+        const int dx = x - R.x[r], dy = y - R.y[r];
+        if (dx < 0 || dy < 0 || dx >= R.w[r] || dy >= R.h[r]) continue;
+        const float v = R.rand[r][((size_t)c * R.h[r] + dy) * R.w[r] + dx];
+        if (R.mode[r] == MDTILE_REGION_BG) { bg += v; bgc += 1.0f; }
+        else { fg += v; fgc += 1.0f; }
+    }
+    const size_t o = (size_t)plane * H * W + px;
+    float out = noise[o];
+    if (bgc > 0.0f) out = bgc > 1.0f ? bg / bgc : bg;
+    if (fgc > 0.0f) out = fgc > 1.0f ? fg / fgc : fg;
+    noise[o] = out;
+}
+}  // namespace
+
+extern "C" int mdtile_region_noise(float* d_noise, int N, int C, int H, int W, const mdtile_region* regions, int num_regions,
+                                   mdtile_stream_t stream) {
+    MDT_CHECK_ARG(d_noise && N > 0 && C > 0 && H > 0 && W > 0 && N * C <= 65535, "mdtile_region_noise: bad shape N=%d C=%d H=%d W=%d", N, C, H, W);
+    MDT_CHECK_ARG(num_regions >= 0 && num_regions <= MAX_NOISE_REGIONS && (num_regions == 0 || regions), "mdtile_region_noise: %d regions (max %d)",
+                  num_regions, MAX_NOISE_REGIONS);
+    if (num_regions == 0) return MDTILE_OK;
+    NoiseRegions R;
+    R.n = num_regions;
+    for (int i = 0; i < num_regions; ++i) {
+        const mdtile_region& g = regions[i];
+        MDT_CHECK_ARG(g.out && g.w > 0 && g.h > 0 && g.x >= 0 && g.y >= 0 && g.x + g.w <= W && g.y + g.h <= H,
+                      "mdtile_region_noise: region %d rect (%d,%d,%d,%d) outside %dx%d or without noise", i, g.x, g.y, g.w, g.h, W, H);
+        MDT_CHECK_ARG(g.mode == MDTILE_REGION_BG || g.mode == MDTILE_REGION_FG, "mdtile_region_noise: region %d has mode %d", i, g.mode);
+        R.x[i] = g.x; R.y[i] = g.y; R.w[i] = g.w; R.h[i] = g.h; R.mode[i] = g.mode; R.rand[i] = (const float*)g.out;
+    }
+    hipLaunchKernelGGL(k_region_noise, dim3(cdiv((long long)H * W, 256), N * C), dim3(256), 0, as_stream(stream), d_noise, C, H, W, R);
+    MDT_LAUNCH_CHECK();
+    return MDTILE_OK;
+}

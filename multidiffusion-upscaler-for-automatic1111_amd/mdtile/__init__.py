@@ -66,6 +66,7 @@ _SIGNATURES = {
     "mdtile_gather_rect": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mdtile_blend": (c_int, [c_void_p, POINTER(_BlendArgs), POINTER(c_void_p), c_int, POINTER(_Region), c_int, c_void_p]),
     "mdtile_blend_finalize": (c_int, [c_void_p, POINTER(_BlendArgs), c_void_p, POINTER(_Region), c_int, c_void_p]),
+    "mdtile_region_noise": (c_int, [c_void_p, c_int, c_int, c_int, c_int, POINTER(_Region), c_int, c_void_p]),
     "mdtile_vae_split_tiles": (c_int, [c_int, c_int, c_int, c_int, _IP, _IP, c_int]),
     "mdtile_gn_stats_ws_size": (c_size_t, [c_int, c_int]),
     "mdtile_gn_stats": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -215,6 +216,22 @@ def weight_map_add_rect(weights: torch.Tensor, x: int, y: int, w: int, h: int, r
         assert rect_w.numel() == w * h
     _check(lib().mdtile_weight_map_add_rect(_p(weights), W, H, x, y, w, h, _p(rect_w), scalar, _stream()),
            "mdtile_weight_map_add_rect")
+
+
+def region_noise(noise: torch.Tensor, regions) -> torch.Tensor:
+    """In-place per-region noise paste (tilediffusion.py:486-529).  noise: [N,C,H,W] fp32 on the GPU;
+    regions: [(x, y, w, h, mode, rand)] with rand = that region's own noise [1,C,h,w] fp32 (same device), in list order."""
+    _dev_tensor(noise, "noise", torch.float32)
+    N, C, H, W = noise.shape
+    arr = (_Region * max(1, len(regions)))()
+    keep = []
+    for i, (x, y, w, h, mode, rand) in enumerate(regions):
+        _dev_tensor(rand, f"regions[{i}].rand", torch.float32)
+        assert tuple(rand.shape) == (1, C, h, w), f"region {i}: noise shape {tuple(rand.shape)} != (1, {C}, {h}, {w})"
+        keep.append(rand)
+        arr[i] = _Region(int(x), int(y), int(w), int(h), int(mode), 0, rand.data_ptr(), None)
+    _check(lib().mdtile_region_noise(_p(noise), N, C, H, W, arr, len(regions), _stream()), "mdtile_region_noise")
+    return noise
 
 
 def reciprocal(x: torch.Tensor) -> torch.Tensor:

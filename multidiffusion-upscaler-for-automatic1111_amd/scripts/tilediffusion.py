@@ -7,8 +7,9 @@ delegates `sampler.model_wrap_cfg.inner_model.forward` / `shared.sd_model.apply_
 stash originals (`create_sampler_original_md`, `apply_model_original_md`), the "Tiled Diffusion" infotext block and the
 in-place restore of `p.width/height` in `postprocess`.
 
-Not carried over (out of the engine's scope, they arm nothing here and only print a notice): Noise Inversion,
-ControlNet / StableSR tensor tiling, per-region seeds (`create_random_tensors` hijack) and the region-config file dialog.
+Per-region seeds (`processing.create_random_tensors` hijack, upstream :376-383, :486-529) run on the engine
+(`mdtile_region_noise`).  Not carried over (out of the engine's scope, they arm nothing here and only print a notice):
+Noise Inversion, ControlNet / StableSR tensor tiling and the region-config file dialog.
 """
 from __future__ import annotations
 
@@ -156,6 +157,13 @@ class Script(scripts.Script):
             name, model, p, Method(method), tile_width, tile_height, overlap, tile_batch_size,
             enable_bbox_control, draw_background, causal_layers, bbox_settings)
 
+        if enable_bbox_control:
+            # every region gets its own seeded initial noise (upstream :376-383)
+            region_info = info.setdefault("Region control", {})
+            Script.create_random_tensors_original_md = processing.create_random_tensors
+            processing.create_random_tensors = lambda *args, **kwargs: self.create_random_tensors_hijack(
+                bbox_settings, region_info, *args, **kwargs)
+
     def postprocess_batch(self, p, enabled, *args, **kwargs):
         if enabled and self.delegate is not None:
             self.delegate.reset_controlnet_tensors()
@@ -195,10 +203,43 @@ class Script(scripts.Script):
               f"{delegate.num_batches or 0} batches" + (f", {len(delegate.custom_bboxes)} regions" if delegate.custom_bboxes else ""))
         return delegate.sampler_raw
 
+    def create_random_tensors_hijack(self, bbox_settings, region_info, shape, seeds, subseeds=None, subseed_strength=0.0,
+                                     seed_resize_from_h=0, seed_resize_from_w=0, p=None):
+        """Upstream :486-529: the job's noise, with every region's rectangle replaced by that region's own noise
+        (`torch.manual_seed(seed)` + CPU `randn`, exactly as upstream draws it); overlapping regions of one kind are
+        averaged, foreground goes on top of background.  The sum / count / average / paste runs in ONE engine launch."""
+        import math
+        import mdtile
+        from modules.processing import get_fixed_seed
+        noise = Script.create_random_tensors_original_md(shape, seeds, subseeds, subseed_strength, seed_resize_from_h,
+                                                         seed_resize_from_w, p)
+        height, width = shape[1], shape[2]
+        regions = []
+        for i, v in bbox_settings.items():
+            seed = get_fixed_seed(v.seed)
+            x, y = max(0, int(v.x * width)), max(0, int(v.y * height))
+            w, h = min(width - x, math.ceil(v.w * width)), min(height - y, math.ceil(v.h * height))
+            torch.manual_seed(seed)
+            rand = torch.randn((1, noise.shape[1], h, w), device=devices.cpu)
+            mode = BlendMode(v.blend_mode)
+            if mode not in (BlendMode.BACKGROUND, BlendMode.FOREGROUND):
+                raise NotImplementedError
+            regions.append((x, y, w, h, mdtile.REGION_BG if mode == BlendMode.BACKGROUND else mdtile.REGION_FG,
+                            rand.to(device=noise.device, dtype=torch.float32).contiguous()))
+            key = "Region " + str(i + 1)
+            if key in region_info:
+                region_info[key]["seed"] = seed
+        work = noise.to(torch.float32).contiguous()
+        mdtile.region_noise(work, regions)
+        return work.to(noise.dtype)
+
     def reset(self, keep_sampler_hijack: bool = False):
         if not keep_sampler_hijack and hasattr(Script, "create_sampler_original_md"):
             sd_samplers.create_sampler = Script.create_sampler_original_md
             del Script.create_sampler_original_md
+        if not keep_sampler_hijack and hasattr(Script, "create_random_tensors_original_md"):
+            processing.create_random_tensors = Script.create_random_tensors_original_md
+            del Script.create_random_tensors_original_md
         MultiDiffusion.unhook()
         MixtureOfDiffusers.unhook()
         self.delegate = None

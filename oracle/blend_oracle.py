@@ -216,3 +216,32 @@ def synthetic_denoiser(x_tile: torch.Tensor) -> torch.Tensor:
 
 def synthetic_region_denoiser(x_region: torch.Tensor, idx: int) -> torch.Tensor:
     return (0.8 - 0.05 * idx) * x_region + 0.2 * x_region.flip(-2)
+
+
+# --------------------------------------------------------------------------------------------------
+# per-region initial noise  (scripts/tilediffusion.py:486-529, create_random_tensors_hijack)
+# --------------------------------------------------------------------------------------------------
+def region_noise(org: torch.Tensor, regions) -> torch.Tensor:
+    """org: [N,C,H,W]; regions: [(fx, fy, fw, fh, mode 'Background'|'Foreground', seed)] as fractions of the canvas.
+    Restates upstream line by line: per-region CPU-seeded randn, per-kind sum + count, average where count > 1,
+    paste background then foreground."""
+    H, W = org.shape[2], org.shape[3]
+    bg, fg = torch.zeros_like(org), torch.zeros_like(org)
+    bgc, fgc = torch.zeros((1, 1, H, W)), torch.zeros((1, 1, H, W))
+    for fx, fy, fw, fh, mode, seed in regions:
+        x, y = int(fx * W), int(fy * H)
+        w, h = math.ceil(fw * W), math.ceil(fh * H)
+        x, y = max(0, x), max(0, y)
+        w, h = min(W - x, w), min(H - y, h)
+        torch.manual_seed(seed)
+        r = torch.randn((1, org.shape[1], h, w))
+        if mode == "Background":
+            bg[:, :, y:y + h, x:x + w] += r
+            bgc[:, :, y:y + h, x:x + w] += 1
+        else:
+            fg[:, :, y:y + h, x:x + w] += r
+            fgc[:, :, y:y + h, x:x + w] += 1
+    bg = torch.where(bgc > 1, bg / bgc, bg)
+    fg = torch.where(fgc > 1, fg / fgc, fg)
+    out = torch.where(bgc > 0, bg, org)
+    return torch.where(fgc > 0, fg, out)

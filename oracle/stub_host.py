@@ -142,6 +142,7 @@ def install(device: str | torch.device | None = None) -> types.ModuleType:
         parse_prompts=lambda prompts: (prompts, {}),
     )
     _mod("modules.sd_samplers_common", InterruptedException=type("InterruptedException", (BaseException,), {}))
+    _mod("modules.images", resize_image=lambda *a, **k: None)
     _mod("modules.sd_samplers", create_sampler=lambda name, model: KDiffusionSampler())
     _mod(
         "modules.processing",
@@ -150,6 +151,7 @@ def install(device: str | torch.device | None = None) -> types.ModuleType:
         StableDiffusionProcessingImg2Img=_Any,
         Processed=_Any,
         create_random_tensors=None,
+        get_fixed_seed=lambda seed: int(seed) if seed not in (None, "", -1) else 1234567,
     )
     _mod("modules.sd_samplers_kdiffusion", KDiffusionSampler=KDiffusionSampler, CFGDenoiser=_Any,
          CFGDenoiserKDiffusion=_Any)
@@ -228,6 +230,11 @@ def load_reference() -> SimpleNamespace:
         md = importlib.import_module("tile_methods.multidiffusion")
         mod = importlib.import_module("tile_methods.mixtureofdiffusers")
         tilevae = importlib.import_module("scripts.tilevae")
+        try:
+            tilediffusion = importlib.import_module("scripts.tilediffusion")   # region-noise hijack (:486-529)
+        except Exception as e:                                                   # pragma: no cover - depends on the stubs
+            tilediffusion = None
+            print(f"[stub_host] upstream scripts/tilediffusion.py not importable under the stub host: {e!r}")
     finally:
         sys.path[:] = old_path
         ref_mods = _evict(_PLUGIN_TOPLEVEL)
@@ -237,7 +244,7 @@ def load_reference() -> SimpleNamespace:
     md.MultiDiffusion.is_edit_model = False
     mod.MixtureOfDiffusers.is_edit_model = False
     _REF_CACHE = SimpleNamespace(utils=utils, attn=attn, abstractdiffusion=absd, multidiffusion=md,
-                                 mixtureofdiffusers=mod, tilevae=tilevae, _modules=ref_mods)
+                                 mixtureofdiffusers=mod, tilevae=tilevae, tilediffusion=tilediffusion, _modules=ref_mods)
     return _REF_CACHE
 
 

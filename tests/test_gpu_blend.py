@@ -198,3 +198,29 @@ def test_errors_are_reported_not_crashed(plugin, cuda):
         E.blend(plan, E.METHOD_MD, [torch.zeros(8, 4, 32, 32, device=cuda)] * plan.num_batches, 2, 4)
     with pytest.raises(E.MdtileError, match="outside"):
         E.gather_rect(torch.zeros(1, 4, 16, 16, device=cuda), 10, 10, 8, 8)
+
+
+REGION_NOISE = [  # fx, fy, fw, fh, mode, seed   (overlapping backgrounds AND overlapping foregrounds, partly off-canvas)
+    (0.0, 0.0, 0.5, 1.0, "Background", 11), (0.3, 0.0, 0.5, 1.0, "Background", 12), (0.6, 0.1, 0.6, 0.8, "Foreground", 13),
+    (0.55, 0.3, 0.2, 0.5, "Foreground", 14), (0.1, 0.7, 0.25, 0.2, "Background", 15),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_region_noise_hijack_bit_exact(plugin, cuda, dtype):
+    """Script.create_random_tensors_hijack on the engine (mdtile_region_noise) == the oracle restatement of upstream
+    tilediffusion.py:486-529 (itself pinned bit-exact to upstream in tests/test_oracle_vs_reference.py)."""
+    td, U = plugin.tilediffusion, plugin.utils
+    torch.manual_seed(5)
+    org = torch.randn(2, 4, 40, 56)
+    td.Script.create_random_tensors_original_md = staticmethod(lambda *a, **k: org.to(cuda, dtype))
+    try:
+        settings = {i: U.BBoxSettings(True, fx, fy, fw, fh, "", "", mode, 0.2, seed) for i, (fx, fy, fw, fh, mode, seed) in enumerate(REGION_NOISE)}
+        info = {f"Region {i + 1}": {} for i in settings}
+        got = td.Script().create_random_tensors_hijack(settings, info, (4, 40, 56), [1, 2])
+    finally:
+        del td.Script.create_random_tensors_original_md
+    assert got.dtype == dtype and got.device.type == "cuda"
+    ref = bo.region_noise(org.to(dtype).float(), REGION_NOISE)
+    assert torch.equal(got.float().cpu(), ref.to(dtype).float())
+    assert [info[f"Region {i + 1}"]["seed"] for i in range(len(REGION_NOISE))] == [r[5] for r in REGION_NOISE]

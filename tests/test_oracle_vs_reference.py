@@ -101,6 +101,31 @@ def test_encoder_task_queue_shape(ref):
     assert sum(1 for t in q if t[0] == "pre_norm") == sum(1 for k, _ in ops if k == "norm")
 
 
+REGION_NOISE = [  # fx, fy, fw, fh, mode, seed   (overlapping backgrounds AND overlapping foregrounds, partly off-canvas)
+    (0.0, 0.0, 0.5, 1.0, "Background", 11), (0.3, 0.0, 0.5, 1.0, "Background", 12), (0.6, 0.1, 0.6, 0.8, "Foreground", 13),
+    (0.55, 0.3, 0.2, 0.5, "Foreground", 14), (0.1, 0.7, 0.25, 0.2, "Background", 15),
+]
+
+
+def test_region_noise_bit_exact(ref):
+    """create_random_tensors_hijack (upstream tilediffusion.py:486-529) == oracle.region_noise."""
+    td = ref.tilediffusion
+    if td is None:
+        pytest.skip("upstream scripts/tilediffusion.py does not import under the stub host")
+    U = ref.utils
+    torch.manual_seed(5)
+    org = torch.randn(2, 4, 40, 56)
+    td.Script.create_random_tensors_original_md = staticmethod(lambda *a, **k: org.clone())
+    try:
+        settings = {i: U.BBoxSettings(True, fx, fy, fw, fh, "", "", mode, 0.2, seed) for i, (fx, fy, fw, fh, mode, seed) in enumerate(REGION_NOISE)}
+        info = {f"Region {i + 1}": {} for i in settings}
+        got = td.Script().create_random_tensors_hijack(settings, info, (4, 40, 56), [1, 2])
+    finally:
+        del td.Script.create_random_tensors_original_md
+    assert torch.equal(got, bo.region_noise(org, REGION_NOISE))
+    assert [info[f"Region {i + 1}"]["seed"] for i in range(len(REGION_NOISE))] == [r[5] for r in REGION_NOISE]
+
+
 def test_gn_and_attn_primitives(ref):
     torch.manual_seed(11)
     t = torch.randn(2, 64, 9, 13) * 3 + 0.5

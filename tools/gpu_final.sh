@@ -17,7 +17,10 @@ cd $R
 cd /tmp
 (timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline 2>&1 | tail -3) > $O/rocprof_$TAG.log 2>&1
 cd $R
+(timeout 300 python probes/encode_probe.py 2>&1 | grep -v amdgpu.ids) > $O/encode_probe_$TAG.log 2>&1
+(timeout 200 python probes/attn_probe.py 30000 71168 77284 2>&1 | grep -v amdgpu.ids) > $O/attn_probe_$TAG.log 2>&1
+(timeout 200 python probes/conv_probe.py --no-exact 2>&1 | grep -v amdgpu.ids) > $O/conv_probe_$TAG.log 2>&1
 find gpurun_out -name "*.db" -delete 2>/dev/null
 rm -rf $O/pmc_fetch_$TAG $O/pmc_write_$TAG
 find gpurun_out -name "*kernel_trace.csv" -size +8M -exec gzip -f {} \;
-tail -6 $O/pytest_gpu_$TAG.log; tail -2 $O/smoke_$TAG.log; tail -8 $O/bench_n2_debug_$TAG.log | cut -c1-600; cat $O/pmc_summary_$TAG.log; tail -1 $O/bench_$TAG.log | cut -c1-2500
+tail -6 $O/pytest_gpu_$TAG.log; tail -2 $O/smoke_$TAG.log; tail -8 $O/bench_n2_debug_$TAG.log | cut -c1-600; cat $O/pmc_summary_$TAG.log; cat $O/encode_probe_$TAG.log; tail -1 $O/bench_$TAG.log | cut -c1-2500
