@@ -68,8 +68,15 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo
 // IB1 = true: ONE input stage instead of two (an extra barrier before the stage is overwritten, once per K-step) and a
 // 128-VGPR budget: 70.8 KB LDS + 128 registers let TWO blocks share a CU (4 waves per SIMD) -- the barrier / LDS-latency
 // stalls of one block are covered by the other block's MFMAs.  Only with MT = 4, TH_ = 8, WDMA.
-template <int MT, int TH_, bool GNS, bool WDMA, bool IB1 = false>  // MT: 32-cout tiles per block, 4 (BM = 128) or 2 (BM = 64); TH_: pixel rows per block, 8 or 16
+// W3 = true (needs WDMA, MT = 4): THREE weight stages -- the DMA of a weight chunk is issued two phases before its use (one
+// phase for one chunk in three), so the L2 / Infinity-Cache latency of the weight stream is covered by a whole extra phase of
+// MFMAs instead of being waited for at every phase boundary.  The loop then uses a raw s_barrier with counted
+// s_waitcnt vmcnt(3) (= "all but this thread's 3 youngest DMA ops have landed"): __syncthreads() would drain every DMA.
+// Counting only the DMA ops this code issues itself keeps the waits correct wherever the compiler places the ordinary
+// (input) loads: additional younger loads can only make vmcnt(3) wait for more, never for less.
+template <int MT, int TH_, bool GNS, bool WDMA, bool IB1 = false, bool W3 = false>  // MT: 32-cout tiles per block, 4 (BM = 128) or 2 (BM = 64); TH_: pixel rows per block, 8 or 16
 __global__ __launch_bounds__(512, IB1 ? 4 : 2) void k_conv3x3_bf16x3(const ConvBParams P) {
+    static_assert(!W3 || (WDMA && MT == 4 && !IB1), "the 3-stage weight ring is built for the DMA path of the 128-cout blocks");
     constexpr int BM = MT * 32;
     constexpr int WAVES_M = MT / 2, WAVES_R = 8 / WAVES_M, NROW = TH_ / WAVES_R;
     constexpr int ROWS_ = TH_ + 2, IN_REC_ = 2 * ROWS_ * COLS;   // halo tile records per hl per stage
@@ -77,8 +84,8 @@ __global__ __launch_bounds__(512, IB1 ? 4 : 2) void k_conv3x3_bf16x3(const ConvB
     constexpr int W_REC = 2 * 3 * MT * 64;              // records per weight chunk (hi block then lo block)
     constexpr int NWREG = (W_REC + 511) / 512;          // 3 (MT = 4) or 2 (MT = 2, half of the threads on the 2nd)
     // LDS (16-byte records): input [2 stages][hl][IN_REC_], weights [2 stages][W_REC]
-    constexpr int IN_STAGE = 2 * IN_REC_, NIST = IB1 ? 1 : 2;
-    __shared__ u32x4 smem[NIST * IN_STAGE + 2 * W_REC];
+    constexpr int IN_STAGE = 2 * IN_REC_, NIST = IB1 ? 1 : 2, WST = W3 ? 3 : 2;
+    __shared__ u32x4 smem[NIST * IN_STAGE + WST * W_REC];
     __shared__ float4 coef_l[GNS ? 2 * MAX_GN_CIN / 4 : 1];   // a[0..Cin) at 0, s[0..Cin) at MAX_GN_CIN
     u32x4* const in_l = smem;
     u32x4* const w_l = smem + NIST * IN_STAGE;
@@ -174,7 +181,7 @@ __global__ __launch_bounds__(512, IB1 ? 4 : 2) void k_conv3x3_bf16x3(const ConvB
             if (wave_u * 64 + 512 * i < W_REC) {   // W_REC is a multiple of 64: whole waves
                 if (WDMA)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + tid + 512 * i),
-                                                     (__attribute__((address_space(3))) void*)(w_l + (ph & 1) * W_REC + wave_u * 64 + 512 * i), 16, 0, 0);
+                                                     (__attribute__((address_space(3))) void*)(w_l + (ph % WST) * W_REC + wave_u * 64 + 512 * i), 16, 0, 0);
                 else
                     rwt[WDMA ? 0 : i] = src[tid + 512 * i];
             }
@@ -201,16 +208,26 @@ __global__ __launch_bounds__(512, IB1 ? 4 : 2) void k_conv3x3_bf16x3(const ConvB
     const int nph = P.NK * 3;
     load_input(0);
     load_weights(0);
+    if (W3 && nph > 1) load_weights(1);
     store_input(0, 0);
-    store_weights(0);
+    store_weights(0);                      // (DMA: vmcnt(0) -- chunks 0 and 1 have landed)
+    if (W3 && P.NK > 1) load_input(1);     // W3 issues the input loads of K-step k+2 at the END of (k, dy = 2), see below
     __syncthreads();
 
     for (int ph = 0; ph < nph; ++ph) {
         const int k = ph / 3, dy = ph - 3 * k;
-        if (dy == 0 && k + 1 < P.NK) load_input(k + 1);
-        if (ph + 1 < nph) load_weights(ph + 1);
+        if (W3) {
+            // chunk ph+2 goes out now (at dy = 2: after this phase's input store, below); its stage held chunk ph-1, which
+            // every wave finished reading before the barrier that closed phase ph-1
+            asm volatile("" ::: "memory");
+            if (dy != 2 && ph + 2 < nph) load_weights(ph + 2);
+            asm volatile("" ::: "memory");
+        } else {
+            if (dy == 0 && k + 1 < P.NK) load_input(k + 1);
+            if (ph + 1 < nph) load_weights(ph + 1);
+        }
 
-        const u32x4* wst = w_l + (ph & 1) * W_REC;
+        const u32x4* wst = w_l + (ph % WST) * W_REC;
         const u32x4* ist = in_l + (IB1 ? 0 : (k & 1)) * IN_STAGE;
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
@@ -234,12 +251,34 @@ __global__ __launch_bounds__(512, IB1 ? 4 : 2) void k_conv3x3_bf16x3(const ConvB
             }
         }
 
-        if (ph + 1 < nph) store_weights((ph + 1) & 1);
-        if (dy == 2 && k + 1 < P.NK) {
-            if (IB1) __syncthreads();      // single input stage: every wave must be done reading K-step k before it is overwritten
-            store_input(IB1 ? 0 : ((k + 1) & 1), k + 1);
+        if (W3) {
+            // chunk ph+1 must have landed.  Younger DMA ops of this thread: the 3 of chunk ph+2 when it was issued at the top of
+            // this phase (dy != 2 and it exists); none otherwise.
+            asm volatile("" ::: "memory");
+            if (ph + 1 < nph) {
+                if (dy != 2 && ph + 2 < nph) __builtin_amdgcn_s_waitcnt(0x0F73);   // vmcnt(3)
+                else __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0)
+            }
+            if (dy == 2 && k + 1 < P.NK) {
+                store_input((k + 1) & 1, k + 1);
+                // the registers are free again: fetch K-step k+2 now (three phases before it is stored).  hipcc drains vmcnt
+                // before ordinary loads while LDS-DMA is in flight; here nothing is in flight (vmcnt(0) just above).
+                if (k + 2 < P.NK) load_input(k + 2);
+            }
+            asm volatile("" ::: "memory");
+            if (dy == 2 && ph + 2 < nph) load_weights(ph + 2);
+            __builtin_amdgcn_s_waitcnt(0xC07F);                                    // lgkmcnt(0): this wave's LDS stores are done
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        } else {
+            if (ph + 1 < nph) store_weights((ph + 1) & 1);
+            if (dy == 2 && k + 1 < P.NK) {
+                if (IB1) __syncthreads();      // single input stage: every wave must be done reading K-step k before it is overwritten
+                store_input(IB1 ? 0 : ((k + 1) & 1), k + 1);
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
 
     // ---- epilogue: + bias (+ residual), store NCHW.  C/D layout of a 32x32 MFMA: col = lane & 31, row = (q&3) + 8*(q>>2) + 4*(lane>>5)
@@ -617,6 +656,14 @@ int conv_bf16x3_launch(const float* d_x, const void* d_w_rec, const float* d_bia
     // measured +3..11 % over the 16-row one-block-per-CU variant on the decoder's shapes (profiles/r1g/conv_probe_r1g.log);
     // MDTILE_CONV_OCC2=0 selects the 16-row variant (MDTILE_CONV_TH / MDTILE_CONV_WDMA then apply)
     static const bool occ2 = [] { const char* e = getenv("MDTILE_CONV_OCC2"); return !(e && strcmp(e, "0") == 0); }();
+    // MDTILE_CONV_W3=1: 16-row blocks, weight DMA through a 3-stage ring (chunks in flight for two phases)
+    static const bool w3 = [] { const char* e = getenv("MDTILE_CONV_W3"); return e && strcmp(e, "1") == 0; }();
+    if (w3 && MT == 4 && th == 16) {
+        if (d_coef) hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 16, true, true, false, true>), grid, block, 0, s, P);
+        else hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 16, false, true, false, true>), grid, block, 0, s, P);
+        MDT_LAUNCH_CHECK();
+        return MDTILE_OK;
+    }
     if (occ2 && MT == 4) {
         P.ptiles = P.PX * ((H + TH - 1) / TH);
         dim3 grid2(((P.ptiles + 7) / 8) * 8 * P.NCB, B);
