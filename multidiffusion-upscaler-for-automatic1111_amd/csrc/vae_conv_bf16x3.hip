@@ -74,7 +74,11 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo
 // s_waitcnt vmcnt(3) (= "all but this thread's 3 youngest DMA ops have landed"): __syncthreads() would drain every DMA.
 // Counting only the DMA ops this code issues itself keeps the waits correct wherever the compiler places the ordinary
 // (input) loads: additional younger loads can only make vmcnt(3) wait for more, never for less.
-template <int MT, int TH_, bool GNS, bool WDMA, bool IB1 = false, bool W3 = false>  // MT: 32-cout tiles per block, 4 (BM = 128) or 2 (BM = 64); TH_: pixel rows per block, 8 or 16
+// ORD: order of the three MFMAs (w_lo x_hi, w_hi x_lo, w_hi x_hi) that feed one accumulator, relative to the other accumulators.
+//   0: as hipcc schedules the straightforward loop nest (it alternates TWO accumulators: every MFMA waits on the one before last)
+//   1: the three MFMAs of an accumulator pinned back to back (scheduling barriers that only MFMAs may not cross)
+//   2: term-major over all accumulators of a tap column (a dependent MFMA is >= 4 MFMAs away); needs every input fragment live
+template <int MT, int TH_, bool GNS, bool WDMA, bool IB1 = false, bool W3 = false, int ORD = 0>  // MT: 32-cout tiles per block, 4 (BM = 128) or 2 (BM = 64); TH_: pixel rows per block, 8 or 16
 __global__ __launch_bounds__(512, IB1 ? 4 : 2) void k_conv3x3_bf16x3(const ConvBParams P) {
     static_assert(!W3 || (WDMA && MT == 4 && !IB1), "the 3-stage weight ring is built for the DMA path of the 128-cout blocks");
     constexpr int BM = MT * 32;
@@ -238,15 +242,35 @@ __global__ __launch_bounds__(512, IB1 ? 4 : 2) void k_conv3x3_bf16x3(const ConvB
                 for (int hl = 0; hl < 2; ++hl) {
                     a[m][hl] = __builtin_bit_cast(bf16x8, wst[((hl * 3 + dx) * MT + wm * 2 + m) * 64 + lane]);
                 }
+            if (ORD == 2) {
+                bf16x8 bh[NROW], bl[NROW];
 #pragma unroll
-            for (int n = 0; n < NROW; ++n) {
-                const int rec = (kg * ROWS_ + wr * NROW + n + dy) * COLS + l31 + dx;
-                const bf16x8 bh = __builtin_bit_cast(bf16x8, ist[rec]), bl = __builtin_bit_cast(bf16x8, ist[IN_REC_ + rec]);
+                for (int n = 0; n < NROW; ++n) {
+                    const int rec = (kg * ROWS_ + wr * NROW + n + dy) * COLS + l31 + dx;
+                    bh[n] = __builtin_bit_cast(bf16x8, ist[rec]);
+                    bl[n] = __builtin_bit_cast(bf16x8, ist[IN_REC_ + rec]);
+                }
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], bh, acc[m][n], 0, 0, 0);   // w_lo * x_hi
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], bl, acc[m][n], 0, 0, 0);   // w_hi * x_lo
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], bh, acc[m][n], 0, 0, 0);   // w_hi * x_hi
+                for (int t = 0; t < 3; ++t) {
+#pragma unroll
+                    for (int n = 0; n < NROW; ++n)
+#pragma unroll
+                        for (int m = 0; m < 2; ++m)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][t == 0 ? 1 : 0], t == 1 ? bl[n] : bh[n], acc[m][n], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0x07F7);   // everything but MFMAs may cross: keeps the term-major order
+                }
+            } else {
+#pragma unroll
+                for (int n = 0; n < NROW; ++n) {
+                    const int rec = (kg * ROWS_ + wr * NROW + n + dy) * COLS + l31 + dx;
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, ist[rec]), bl = __builtin_bit_cast(bf16x8, ist[IN_REC_ + rec]);
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], bh, acc[m][n], 0, 0, 0);   // w_lo * x_hi
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], bl, acc[m][n], 0, 0, 0);   // w_hi * x_lo
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], bh, acc[m][n], 0, 0, 0);   // w_hi * x_hi
+                        if (ORD == 1) __builtin_amdgcn_sched_barrier(0x07F7);   // MFMAs stay put: the triple issues back to back
+                    }
                 }
             }
         }
@@ -664,11 +688,31 @@ int conv_bf16x3_launch(const float* d_x, const void* d_w_rec, const float* d_bia
         MDT_LAUNCH_CHECK();
         return MDTILE_OK;
     }
+    static const int ord = [] { const char* e = getenv("MDTILE_CONV_ORD"); return e ? atoi(e) : 0; }();
     if (occ2 && MT == 4) {
         P.ptiles = P.PX * ((H + TH - 1) / TH);
         dim3 grid2(((P.ptiles + 7) / 8) * 8 * P.NCB, B);
-        if (d_coef) hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 8, true, true, true>), grid2, block, 0, s, P);
-        else hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 8, false, true, true>), grid2, block, 0, s, P);
+        if (ord == 1) {
+            if (d_coef) hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 8, true, true, true, false, 1>), grid2, block, 0, s, P);
+            else hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 8, false, true, true, false, 1>), grid2, block, 0, s, P);
+        } else if (ord == 2) {
+            if (d_coef) hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 8, true, true, true, false, 2>), grid2, block, 0, s, P);
+            else hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 8, false, true, true, false, 2>), grid2, block, 0, s, P);
+        } else {
+            if (d_coef) hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 8, true, true, true>), grid2, block, 0, s, P);
+            else hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 8, false, true, true>), grid2, block, 0, s, P);
+        }
+        MDT_LAUNCH_CHECK();
+        return MDTILE_OK;
+    }
+    if (ord != 0 && MT == 4 && th == 16) {   // 16-row blocks (MDTILE_CONV_OCC2=0): same two orders
+        if (ord == 1) {
+            if (d_coef) hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 16, true, true, false, false, 1>), grid, block, 0, s, P);
+            else hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 16, false, true, false, false, 1>), grid, block, 0, s, P);
+        } else {
+            if (d_coef) hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 16, true, true, false, false, 2>), grid, block, 0, s, P);
+            else hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 16, false, true, false, false, 2>), grid, block, 0, s, P);
+        }
         MDT_LAUNCH_CHECK();
         return MDTILE_OK;
     }
