@@ -688,7 +688,8 @@ int conv_bf16x3_launch(const float* d_x, const void* d_w_rec, const float* d_bia
         MDT_LAUNCH_CHECK();
         return MDTILE_OK;
     }
-    static const int ord = [] { const char* e = getenv("MDTILE_CONV_ORD"); return e ? atoi(e) : 0; }();
+    // MFMA order: term-major across the accumulators by default (+1..4 % measured, profiles/r1l); MDTILE_CONV_ORD=0: hipcc's own
+    static const int ord = [] { const char* e = getenv("MDTILE_CONV_ORD"); return e ? atoi(e) : 2; }();
     if (occ2 && MT == 4) {
         P.ptiles = P.PX * ((H + TH - 1) / TH);
         dim3 grid2(((P.ptiles + 7) / 8) * 8 * P.NCB, B);

@@ -18,9 +18,13 @@ cd /tmp
 (timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline 2>&1 | tail -3) > $O/rocprof_$TAG.log 2>&1
 cd $R
 (timeout 300 python probes/encode_probe.py 2>&1 | grep -v amdgpu.ids) > $O/encode_probe_$TAG.log 2>&1
+(timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile-pass --slow-vae 2>&1 | tail -1 | cut -c1-900 | sed "s/^/slow-mode GroupNorm: /") > $O/bench_extra_$TAG.log 2>&1
+(timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile-pass --method mod 2>&1 | tail -1 | cut -c1-900 | sed "s/^/Mixture of Diffusers blend: /") >> $O/bench_extra_$TAG.log 2>&1
+(timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile-pass --latent 512 --tile 96 --overlap 48 --method mod 2>&1 | tail -1 | cut -c1-900 | sed "s/^/cfg3 4096x4096 MoD 96\/48 + tiled decode: /") >> $O/bench_extra_$TAG.log 2>&1
+(timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile-pass --latent 256 --tile 96 --overlap 48 --no-vae 2>&1 | tail -1 | cut -c1-900 | sed "s/^/cfg2 2048x2048 MD 96\/48 blend only: /") >> $O/bench_extra_$TAG.log 2>&1
 (timeout 200 python probes/attn_probe.py 30000 71168 77284 2>&1 | grep -v amdgpu.ids) > $O/attn_probe_$TAG.log 2>&1
 (timeout 200 python probes/conv_probe.py --no-exact 2>&1 | grep -v amdgpu.ids) > $O/conv_probe_$TAG.log 2>&1
 find gpurun_out -name "*.db" -delete 2>/dev/null
 rm -rf $O/pmc_fetch_$TAG $O/pmc_write_$TAG
 find gpurun_out -name "*kernel_trace.csv" -size +8M -exec gzip -f {} \;
-tail -6 $O/pytest_gpu_$TAG.log; tail -2 $O/smoke_$TAG.log; tail -8 $O/bench_n2_debug_$TAG.log | cut -c1-600; cat $O/pmc_summary_$TAG.log; cat $O/encode_probe_$TAG.log; tail -1 $O/bench_$TAG.log | cut -c1-2500
+tail -6 $O/pytest_gpu_$TAG.log; tail -2 $O/smoke_$TAG.log; tail -8 $O/bench_n2_debug_$TAG.log | cut -c1-600; cat $O/pmc_summary_$TAG.log; cat $O/encode_probe_$TAG.log; cat $O/bench_extra_$TAG.log; tail -1 $O/bench_$TAG.log | cut -c1-2500
