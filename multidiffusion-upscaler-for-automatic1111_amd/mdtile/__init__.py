@@ -126,6 +126,13 @@ def _check(rc: int, what: str):
         raise MdtileError(f"{what} failed (rc={rc}): {lib().mdtile_last_error().decode(errors='replace')}")
 
 
+def require_device(dev) -> None:
+    """The engine only runs on the GPU: callers check up front instead of failing inside the first kernel wrapper."""
+    if torch.device(dev).type != "cuda":
+        raise MdtileError(f"the mdtile engine needs its tensors on the GPU, got device {dev} (no CPU fallback exists; "
+                          "for Tiled VAE enable 'Move VAE to GPU')")
+
+
 def _dev_tensor(t: torch.Tensor, name: str, dtype=None) -> torch.Tensor:
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name} must be a tensor")

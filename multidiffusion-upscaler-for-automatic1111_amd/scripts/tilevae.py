@@ -65,8 +65,9 @@ class Step:
 class AttnPack:
     """q/k/v/proj_out of one AttnBlock, packed for the engine; v is produced token-major for the PV contraction."""
 
-    def __init__(self, attn, pack=None):
+    def __init__(self, attn, pack=None, engine=None):
         pack = pack or _pack
+        self.engine = engine or mdtile
         self.q, self.k, self.v, self.proj = (pack(attn.q), pack(attn.k), pack(attn.v), pack(attn.proj_out))
         self.channels = attn.q.weight.shape[0]
 
@@ -75,7 +76,7 @@ class AttnPack:
         q = self.q(h).view(B, C, H * W)
         k = self.k(h).view(B, C, H * W)
         v = self.v(h, token_major=True)
-        o = mdtile.vae_attn(q, k, v, float(int(C) ** (-0.5)))          # softmax(q^T k / sqrt(C)) v   (attn.py:55-67)
+        o = self.engine.vae_attn(q, k, v, float(int(C) ** (-0.5)))     # softmax(q^T k / sqrt(C)) v   (attn.py:55-67)
         return self.proj(o.view(B, C, H, W), residual=residual)        # proj_out + the queue's add_res
 
 
@@ -110,18 +111,18 @@ def _resblock(steps: List[Step], blk, pack):
     steps.append(Step("conv", conv=pack(blk.conv2), fuse_res=True))       # conv2 + add_res in one epilogue
 
 
-def build_task_queue(net, is_decoder: bool = True, pack=None) -> List[Step]:
+def build_task_queue(net, is_decoder: bool = True, pack=None, engine=None) -> List[Step]:
     """Linearise an ldm Decoder exactly in upstream's order (:139-195): conv_in, mid(res, attn, res), levels top-down
     with num_res_blocks+1 resblocks (+ upsample except on level 0), norm_out, silu, conv_out.  30 norms for SD/SDXL.
-    `pack` turns an nn.Conv2d into the callable a step carries (default: engine weights, mdtile.PackedConv; the CPU tests
-    of the multi-GPU host logic inject their own)."""
+    `pack` turns an nn.Conv2d into the callable a step carries and `engine` is the module the attention step calls
+    (defaults: mdtile.PackedConv / mdtile; the CPU tests of the host logic inject torch doubles, tests/torch_engine.py)."""
     pack = pack or _pack
     steps = [Step("conv", conv=pack(net.conv_in))]
 
     def _mid():
         _resblock(steps, net.mid.block_1, pack)
         steps.extend([Step("store_res"), Step("norm", norm=_norm_params(net.mid.attn_1.norm)),
-                      Step("attn", attn=AttnPack(net.mid.attn_1, pack))])
+                      Step("attn", attn=AttnPack(net.mid.attn_1, pack, engine))])
         _resblock(steps, net.mid.block_2, pack)
 
     if is_decoder:
@@ -167,11 +168,12 @@ def crop_valid_region(x, input_bbox, target_bbox, is_decoder):
 class GroupNormParam:
     """Slow-mode collector: per-tile (var, mean) rows pooled by pixel count (upstream :289-335)."""
 
-    def __init__(self):
+    def __init__(self, engine=None):
+        self.engine = engine or mdtile
         self.var_list, self.mean_list, self.pixel_list = [], [], []
 
     def add_tile(self, tile: Tensor):
-        var, mean = get_var_mean(tile, 32)
+        var, mean = self.engine.gn_stats(tile, 32)
         self.var_list.append(var)
         self.mean_list.append(mean)
         self.pixel_list.append(tile.shape[2] * tile.shape[3])
@@ -179,7 +181,7 @@ class GroupNormParam:
     def summary(self) -> Optional[Tuple[Tensor, Tensor]]:
         if not self.var_list:
             return None
-        return mdtile.gn_pool(torch.vstack(self.mean_list), torch.vstack(self.var_list), self.pixel_list)
+        return self.engine.gn_pool(torch.vstack(self.mean_list), torch.vstack(self.var_list), self.pixel_list)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -194,7 +196,12 @@ class TileState:
 class VAEHook:
 
     def __init__(self, net, tile_size, is_decoder: bool, fast_decoder: bool, fast_encoder: bool, color_fix: bool,
-                 to_gpu: bool = False):
+                 to_gpu: bool = False, engine=None, pack=None, sp_ops=None):
+        # engine / pack / sp_ops: the mdtile module, the conv packer and the sequence-parallel ops.  The product never passes
+        # them (defaults = the HIP engine, GPU only); the CPU tests of this host logic inject torch doubles.
+        self.engine = engine or mdtile
+        self._pack = pack
+        self._sp_ops = sp_ops
         self.net = net
         self.tile_size = tile_size
         self.is_decoder = is_decoder
@@ -233,13 +240,13 @@ class VAEHook:
         return lowerbound
 
     def split_tiles(self, h, w):
-        return mdtile.vae_split_tiles(h, w, self.tile_size, self.is_decoder)
+        return self.engine.vae_split_tiles(h, w, self.tile_size, self.is_decoder)
 
     # ---- program ------------------------------------------------------------------------------------------------------
     def program(self) -> List[Step]:
         dev = next(self.net.parameters()).device
         if self._program is None or self._program_dev != dev:
-            self._program = build_task_queue(self.net, self.is_decoder)
+            self._program = build_task_queue(self.net, self.is_decoder, self._pack, self.engine)
             self._program_dev = dev
         return self._program
 
@@ -264,18 +271,18 @@ class VAEHook:
                 st.x = torch.tanh(st.x)
             st.pc += 1
 
-    @staticmethod
-    def _apply_norm(steps: List[Step], st: TileState, var: Tensor, mean: Tensor):
+    def _apply_norm(self, steps: List[Step], st: TileState, var: Tensor, mean: Tensor):
+        E = self.engine
         s = steps[st.pc]
         gamma, beta = s.norm
         nxt = steps[st.pc + 1] if st.pc + 1 < len(steps) else None
         if (FUSE_PRE_GN and s.silu and nxt is not None and nxt.kind == "conv" and not nxt.downsample
                 and nxt.conv.fuses_pre_gn(upsample2x=nxt.upsample)):
             # norm + SiLU ride on the conv's input staging: only the per-channel (a, s) pair is formed here
-            st.pre = mdtile.gn_coeffs(mean, var, gamma, beta, st.x.shape[1], 32, 1e-6)
+            st.pre = E.gn_coeffs(mean, var, gamma, beta, st.x.shape[1], 32, 1e-6)
         else:
             keep = st.res and st.res[-1] is st.x          # identity shortcut: the residual aliases the pre-norm tensor
-            st.x = mdtile.gn_apply(st.x, mean, var, gamma, beta, 32, 1e-6, s.silu, out=None if keep else st.x)
+            st.x = E.gn_apply(st.x, mean, var, gamma, beta, 32, 1e-6, s.silu, out=None if keep else st.x)
         st.pc += 1
 
     @torch.no_grad()
@@ -294,7 +301,7 @@ class VAEHook:
             self._run_until_norm(steps, st)
             if st.pc >= len(steps):
                 break
-            var, mean = get_var_mean(st.x, 32)
+            var, mean = self.engine.gn_stats(st.x, 32)
             frozen.append((var, mean))
             if len(frozen) == n_norm:
                 break
@@ -330,8 +337,8 @@ class VAEHook:
         net = self.net
         dev = next(net.parameters()).device
         dtype = next(net.parameters()).dtype
-        if dev.type != "cuda":
-            raise mdtile.MdtileError("Tiled VAE (mdtile engine) needs the VAE on the GPU; enable 'Move VAE to GPU'")
+        E = self.engine
+        E.require_device(dev)      # the HIP engine: raises unless the VAE sits on the GPU (no CPU path exists)
         z = z.detach().to(device=dev, dtype=torch.float32).contiguous()
         N, _, height, width = z.shape
         net.last_z_shape = z.shape
@@ -341,19 +348,19 @@ class VAEHook:
 
         frozen = None
         if self.fast_mode:
-            zs = mdtile.vae_fast_input(z, self.tile_size)
+            zs = E.vae_fast_input(z, self.tile_size)
             print(f"[Tiled VAE]: Fast mode enabled, estimating group norm parameters on {zs.shape[3]} x {zs.shape[2]} image")
             rank, world = self.shard
             if world > 1 and SP_ESTIMATOR and self.is_decoder and zs.shape[2] >= 2 * world:
                 # the estimator is one untiled pass: split it by rows across the ranks instead of repeating it on each
                 from mdtile import seqpar
-                frozen = seqpar.estimate_group_norm_sp(steps, zs, seqpar.BandComm(rank, world), seqpar.EngineOps(), FUSE_PRE_GN)
+                frozen = seqpar.estimate_group_norm_sp(steps, zs, seqpar.BandComm(rank, world), self._sp_ops or seqpar.EngineOps(), FUSE_PRE_GN)
             else:
                 frozen = self.estimate_group_norm(zs, steps)
 
         rank, world = self.shard
         mine = list(range(len(in_bboxes))) if world == 1 else list(range(rank, len(in_bboxes), world))
-        tiles = {i: TileState(mdtile.gather_rect(z, b[0], b[2], b[1] - b[0], b[3] - b[2])) for i, b in enumerate(in_bboxes) if i in set(mine)}
+        tiles = {i: TileState(E.gather_rect(z, b[0], b[2], b[1] - b[0], b[3] - b[2])) for i, b in enumerate(in_bboxes) if i in set(mine)}
         result = None
         interrupted = False
 
@@ -364,7 +371,7 @@ class VAEHook:
                 oh, ow = (height * 8, width * 8) if self.is_decoder else (height // 8, width // 8)
                 result = torch.zeros((N, x.shape[1], oh, ow), device=dev, dtype=torch.float32)
             devices.test_for_nans(x, "vae")
-            mdtile.crop_store(x, in_bboxes[i], out_bboxes[i], result, self.is_decoder)
+            E.crop_store(x, in_bboxes[i], out_bboxes[i], result, self.is_decoder)
             tiles[i] = None
 
         n_norm_total = sum(1 for s in steps if s.kind == "norm")
@@ -389,7 +396,7 @@ class VAEHook:
             k_norm = 0
             while not interrupted:
                 use_frozen = frozen is not None and k_norm < len(frozen)
-                gp = GroupNormParam()
+                gp = GroupNormParam(E)
                 for i in (mine if forward else reversed(mine)):
                     if state.interrupted:
                         interrupted = True
@@ -422,8 +429,9 @@ class VAEHook:
             approx = torch.cat([torch.nn.functional.interpolate(cheap_approximation(x).unsqueeze(0), scale_factor=8,
                                                                 mode="nearest-exact") for x in z], dim=0)
             return approx.to(dev, dtype=dtype)
-        torch.cuda.synchronize(dev)
-        print(f"[Tiled VAE]: Done in {time() - t0:.3f}s, max VRAM alloc {torch.cuda.max_memory_allocated(dev) / 2**20:.3f} MB")
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+            print(f"[Tiled VAE]: Done in {time() - t0:.3f}s, max VRAM alloc {torch.cuda.max_memory_allocated(dev) / 2**20:.3f} MB")
         return result.to(dtype)
 
 

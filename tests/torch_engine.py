@@ -1,0 +1,124 @@
+"""Torch doubles of the engine surface the HOST logic calls (test infrastructure).
+
+The product's VAEHook / seqpar executor talk to the `mdtile` module (HIP, GPU only).  The CPU tests of that host logic --
+tile scheduling, fast / slow / semi-fast GroupNorm handling, crop + assemble, tile sharding and the sequence-parallel
+estimator across ranks -- inject these plain-torch stand-ins with the same call signatures, so the logic is checked
+against the oracle without a GPU.  Nothing here is imported by the product."""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from oracle import vae_oracle as vo
+
+
+class TorchConv:
+    """Stand-in for mdtile.PackedConv around an nn.Conv2d."""
+
+    def __init__(self, conv):
+        self.conv = conv
+        self.ksize = conv.kernel_size[0]
+        self.cin, self.cout = conv.in_channels, conv.out_channels
+        # ldm Downsample.conv has stride 2 / padding 0; everything else is 'same' stride 1
+        self.down = conv.stride == (2, 2)
+
+    def fuses_pre_gn(self, upsample2x=False, token_major=False, exact=False):
+        return self.ksize == 3 and not self.down and not upsample2x and not token_major and self.cin % 16 == 0 and self.cout >= 32
+
+    def __call__(self, x, residual=None, upsample2x=False, token_major=False, exact=False, pre_gn=None):
+        if pre_gn is not None:
+            x = F.silu(x * pre_gn[:, 0, :, None, None] + pre_gn[:, 1, :, None, None])
+        if upsample2x:
+            x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+        y = self.conv(x)
+        if residual is not None:
+            y = y + residual
+        if token_major:
+            B, C, H, W = y.shape
+            y = y.permute(0, 2, 3, 1).reshape(B, H * W, C).contiguous()
+        return y
+
+    def down2(self, x):
+        return self.conv(F.pad(x, (0, 1, 0, 1)))
+
+
+class TorchEngine:
+    """Stand-in for the `mdtile` module as scripts/tilevae.py uses it."""
+
+    class MdtileError(RuntimeError):
+        pass
+
+    def require_device(self, dev):
+        return None
+
+    def vae_split_tiles(self, h, w, tile_size, is_decoder):
+        return vo.split_tiles(h, w, tile_size, is_decoder)
+
+    def vae_fast_input(self, z, tile_size):
+        return vo.fast_mode_input(z, tile_size)
+
+    def gather_rect(self, z, x, y, w, h):
+        return z[:, :, y:y + h, x:x + w].clone()
+
+    def crop_store(self, tile, in_bbox, out_bbox, result, is_decoder=True):
+        result[:, :, out_bbox[2]:out_bbox[3], out_bbox[0]:out_bbox[1]] = vo.crop_valid_region(tile, in_bbox, out_bbox, is_decoder)
+
+    def gn_stats(self, x, groups=32):
+        return vo.get_var_mean(x, groups)
+
+    def gn_pool(self, means, vars_, pixels):
+        return vo.pool_stats(list(vars_), list(means), pixels)
+
+    def gn_coeffs(self, mean, var, gamma, beta, C, groups=32, eps=1e-6):
+        B = mean.numel() // groups
+        cpg = C // groups
+        rstd = 1.0 / torch.sqrt(var.view(B, groups, 1) + eps)
+        g = gamma.view(1, groups, cpg) if gamma is not None else torch.ones(1, groups, cpg)
+        b = beta.view(1, groups, cpg) if beta is not None else torch.zeros(1, groups, cpg)
+        a = (rstd * g).reshape(B, C)
+        s = (b - mean.view(B, groups, 1) * a.view(B, groups, cpg)).reshape(B, C)
+        return torch.stack([a, s], dim=1)
+
+    def gn_apply(self, x, mean, var, gamma, beta, groups=32, eps=1e-6, silu=False, out=None):
+        y = vo.custom_group_norm(x, groups, mean, var, gamma, beta, eps)
+        y = F.silu(y) if silu else y
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
+
+    def vae_attn(self, q, k, v_tok, scale):
+        w = torch.softmax(torch.bmm(q.permute(0, 2, 1), k) * scale, dim=2)
+        return torch.bmm(w, v_tok).permute(0, 2, 1).contiguous()
+
+
+class TorchSeqParOps:
+    """Stand-in for mdtile.seqpar.EngineOps (the ops interface of estimate_group_norm_sp)."""
+
+    def ksize(self, conv):
+        return conv.ksize
+
+    def fuses_pre_gn(self, conv, upsample):
+        return conv.fuses_pre_gn(upsample2x=upsample)
+
+    def conv(self, conv, x, residual=None, upsample2x=False, pre_gn=None, token_major=False):
+        return conv(x, residual=residual, upsample2x=upsample2x, token_major=token_major, pre_gn=pre_gn)
+
+    def gn_sums(self, x, row_lo, row_hi):
+        B = x.shape[0]
+        v = x[:, :, row_lo:row_hi, :].double().reshape(B * 32, -1)
+        return torch.stack([v.sum(1), (v * v).sum(1)], dim=1)
+
+    def gn_from_sums(self, sums, count):
+        m = sums[:, 0] / count
+        v = (sums[:, 1] / count - m * m).clamp_min(0.0)
+        return v.float(), m.float()
+
+    def gn_coeffs(self, mean, var, gamma, beta, C):
+        return TorchEngine().gn_coeffs(mean, var, gamma, beta, C)
+
+    def gn_apply(self, x, mean, var, gamma, beta, silu, inplace):
+        return TorchEngine().gn_apply(x, mean, var, gamma, beta, 32, 1e-6, silu)
+
+    def attn_qk(self, q, k, v_tok, scale):
+        return TorchEngine().vae_attn(q, k, v_tok, scale)
