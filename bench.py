@@ -13,9 +13,13 @@ The UNet itself is out of scope: the blend consumes pre-ge
 offline).  Inputs are resident in HBM before the timed region; nothing is cached between steps.
 
 N > 1: strong scaling of the same image -- diffusion tiles in row bands per rank with a neighbour halo exchange of the
-overlap-row partial sums, VAE tiles dealt round-robin, outputs left sharded (mdtile/sharding.py).
-The JSON line carries `roofline` (dominant kernel: the fp32-MFMA 3x3 conv), `roofline_blend` (HBM-bound blend kernel) and
-`cpu_baseline` (the oracle = CPU port of the reference algorithm, timed on this box's host cores on a bounded sample).
+overlap-row partial sums, VAE tiles dealt round-robin, the fast-mode GroupNorm estimator split by rows across the ranks
+(mdtile/seqpar.py), outputs left sharded (mdtile/sharding.py).
+The JSON line carries `roofline` (the kernel class with the largest share of the step: the split-bf16 MFMA 3x3 conv;
+flops = the ones executed, peak = 2500/3 TFLOP/s for a kernel that spends 3 bf16 MFMAs per product; `traffic` = HBM bytes
+per launch when MDTILE_PMC_SUMMARY points at tools/pmc_summary.py's json of a previous rocprofv3 --pmc pass),
+`roofline_blend` (the HBM-bound blend kernel) and `cpu_baseline` (the oracle = CPU port of the reference algorithm, timed
+on this box's host cores on a bounded sample).
 """
 from __future__ import annotations
 

@@ -196,12 +196,13 @@ class TileState:
 class VAEHook:
 
     def __init__(self, net, tile_size, is_decoder: bool, fast_decoder: bool, fast_encoder: bool, color_fix: bool,
-                 to_gpu: bool = False, engine=None, pack=None, sp_ops=None):
-        # engine / pack / sp_ops: the mdtile module, the conv packer and the sequence-parallel ops.  The product never passes
-        # them (defaults = the HIP engine, GPU only); the CPU tests of this host logic inject torch doubles.
-        self.engine = engine or mdtile
-        self._pack = pack
-        self._sp_ops = sp_ops
+                 to_gpu: bool = False):
+        # (signature == upstream's, :364-372.)  engine / _pack / _sp_ops: the mdtile module, the conv packer and the
+        # sequence-parallel ops the hook talks to.  The product leaves the defaults (the HIP engine, GPU only); the CPU tests of
+        # this host logic overwrite the three attributes with torch doubles (tests/torch_engine.py).
+        self.engine = mdtile
+        self._pack = None
+        self._sp_ops = None
         self.net = net
         self.tile_size = tile_size
         self.is_decoder = is_decoder

@@ -24,8 +24,9 @@ def _hook(net, ts, is_decoder, fast, color_fix=False):
     sh.install("cpu")
     pl = sh.load_plugin()
     net.original_forward = net.forward
-    return pl.tilevae.VAEHook(net, ts, is_decoder=is_decoder, fast_decoder=fast, fast_encoder=fast, color_fix=color_fix,
-                              engine=te.TorchEngine(), pack=te.TorchConv, sp_ops=te.TorchSeqParOps())
+    hook = pl.tilevae.VAEHook(net, ts, is_decoder=is_decoder, fast_decoder=fast, fast_encoder=fast, color_fix=color_fix)
+    hook.engine, hook._pack, hook._sp_ops = te.TorchEngine(), te.TorchConv, te.TorchSeqParOps()   # torch doubles of the engine
+    return hook
 
 
 @pytest.mark.parametrize("fast", [True, False])
