@@ -338,3 +338,33 @@ def test_tiled_encode_full_width_encoder(plugin, cuda, fast, color_fix):
     assert out.shape == ref.shape
     err = _rel(out, ref)
     assert err < 1e-3, f"full-width tiled encode (fast={fast}, color_fix={color_fix}): rel err {err}"
+
+
+@pytest.mark.parametrize("fast", [True, False])
+def test_tiled_decode_batch_of_two(plugin, cuda, fast):
+    """N = 2 latents in one call (upstream's buffers are [N, ...] throughout; statistics are per sample)."""
+    dec_cpu = ld.make_decoder(5, small=True)
+    torch.manual_seed(8)
+    z = torch.randn(2, 4, 36, 44)
+    ref = vo.tiled_forward(dec_cpu, z, 16, fast)
+    dec = ld.make_decoder(5, small=True).to(cuda)
+    dec.original_forward = dec.forward
+    hook = plugin.tilevae.VAEHook(dec, 16, is_decoder=True, fast_decoder=fast, fast_encoder=False, color_fix=False)
+    out = hook(z.to(cuda)).cpu()
+    assert out.shape == ref.shape
+    assert _rel(out, ref) < 1e-3
+
+
+def test_tiled_decode_half_precision_vae(plugin, cuda):
+    """A webui without --no-half-vae hands over an fp16 decoder: weights are taken as they are (fp16 values), the engine
+    computes in fp32 / split-bf16 and the result comes back in the net's dtype (upstream :656)."""
+    dec_cpu = ld.make_decoder(6, small=True).half().float()          # the fp16-rounded weights, fp32 arithmetic
+    torch.manual_seed(9)
+    z = torch.randn(1, 4, 36, 44)
+    ref = vo.tiled_forward(dec_cpu, z.half().float(), 16, True)
+    dec = ld.make_decoder(6, small=True).half().to(cuda)
+    dec.original_forward = dec.forward
+    hook = plugin.tilevae.VAEHook(dec, 16, is_decoder=True, fast_decoder=True, fast_encoder=False, color_fix=False)
+    out = hook(z.half().to(cuda))
+    assert out.dtype == torch.float16
+    assert _rel(out.float().cpu(), ref) < 2e-3                          # + one fp16 rounding of the output
