@@ -20,7 +20,7 @@ VAE decode: tiles are dealt round-robin; the fast-mode statistics estimator (one
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import List, Optional, Sequence, Tuple
+from typing import List, Sequence, Tuple
 
 import torch
 import torch.distributed as dist

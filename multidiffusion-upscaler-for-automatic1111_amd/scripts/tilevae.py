@@ -18,7 +18,6 @@ upstream :492-496).
 """
 from __future__ import annotations
 
-import math
 from time import time
 from typing import List, Optional, Tuple
 
