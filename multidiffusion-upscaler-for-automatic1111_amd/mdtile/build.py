@@ -34,7 +34,7 @@ def _digest() -> str:
     h = hashlib.sha256()
     for f in _sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(INCLUDE, "mdtile.h")]:
         with open(f, "rb") as fh:
-            h.update(f.encode())
+            h.update(os.path.basename(f).encode())   # not the absolute path: the tree is copied around (gpurun snapshot, extensions/)
             h.update(fh.read())
     h.update(" ".join(HIPCC_FLAGS).encode())
     return h.hexdigest()
