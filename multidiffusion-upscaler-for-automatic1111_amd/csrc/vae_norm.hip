@@ -207,22 +207,26 @@ __device__ __forceinline__ int nearest_exact_src(int dst, float scale, int in_si
     return s < in_size - 1 ? s : in_size - 1;
 }
 
+constexpr int FAST_NBLK = 128;   // partial blocks per channel (the encoder runs this on a whole 8K image: 67 M elements per channel)
+
+// stage 1: block (blk, c) accumulates its grid-stride share of channel c: fp64 sums of z and of the down-sampled z, min / max
 __global__ __launch_bounds__(256) void k_fast_stats(const float* __restrict__ z, int N, int C, int H, int W, int oh, int ow,
-                                                    float sc_h, float sc_w, double* __restrict__ wsd, float* __restrict__ wsf) {
+                                                    float sc_h, float sc_w, double* __restrict__ pd, float* __restrict__ pf) {
     __shared__ double sh[4];
     __shared__ float shf[8];
-    const int c = blockIdx.x;
+    const int c = blockIdx.y, blk = blockIdx.x;
     double s1 = 0, s2 = 0, d1 = 0, d2 = 0;
     float mn = INFINITY, mx = -INFINITY;
+    const size_t stride = (size_t)FAST_NBLK * 256, start = (size_t)blk * 256 + threadIdx.x;
     for (int n = 0; n < N; ++n) {
         const float* p = z + ((size_t)n * C + c) * H * W;
-        for (size_t i = threadIdx.x; i < (size_t)H * W; i += 256) {
+        for (size_t i = start; i < (size_t)H * W; i += stride) {
             float v = p[i];
             s1 += v; s2 += (double)v * v;
             mn = fminf(mn, v); mx = fmaxf(mx, v);
         }
-        for (int i = threadIdx.x; i < oh * ow; i += 256) {
-            int oy = i / ow, ox = i - oy * ow;
+        for (size_t i = start; i < (size_t)oh * ow; i += stride) {
+            int oy = (int)(i / ow), ox = (int)(i - (size_t)oy * ow);
             float v = p[(size_t)nearest_exact_src(oy, sc_h, H) * W + nearest_exact_src(ox, sc_w, W)];
             d1 += v; d2 += (double)v * v;
         }
@@ -233,10 +237,29 @@ __global__ __launch_bounds__(256) void k_fast_stats(const float* __restrict__ z,
     if ((threadIdx.x & 63) == 0) { shf[threadIdx.x >> 6] = mn; shf[4 + (threadIdx.x >> 6)] = mx; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        wsd[c * 4 + 0] = s1; wsd[c * 4 + 1] = s2; wsd[c * 4 + 2] = d1; wsd[c * 4 + 3] = d2;
-        wsf[c] = fminf(fminf(shf[0], shf[1]), fminf(shf[2], shf[3]));
-        wsf[C + c] = fmaxf(fmaxf(shf[4], shf[5]), fmaxf(shf[6], shf[7]));
+        double* o = pd + ((size_t)c * FAST_NBLK + blk) * 4;
+        o[0] = s1; o[1] = s2; o[2] = d1; o[3] = d2;
+        pf[((size_t)c * FAST_NBLK + blk) * 2 + 0] = fminf(fminf(shf[0], shf[1]), fminf(shf[2], shf[3]));
+        pf[((size_t)c * FAST_NBLK + blk) * 2 + 1] = fmaxf(fmaxf(shf[4], shf[5]), fmaxf(shf[6], shf[7]));
     }
+}
+
+// stage 2: one thread per channel combines the partials in a fixed order (deterministic)
+__global__ void k_fast_combine(const double* __restrict__ pd, const float* __restrict__ pf, int C, double* __restrict__ wsd,
+                               float* __restrict__ wsf) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a[4] = {0, 0, 0, 0};
+    float mn = INFINITY, mx = -INFINITY;
+    for (int b = 0; b < FAST_NBLK; ++b) {
+        const double* o = pd + ((size_t)c * FAST_NBLK + b) * 4;
+        a[0] += o[0]; a[1] += o[1]; a[2] += o[2]; a[3] += o[3];
+        mn = fminf(mn, pf[((size_t)c * FAST_NBLK + b) * 2 + 0]);
+        mx = fmaxf(mx, pf[((size_t)c * FAST_NBLK + b) * 2 + 1]);
+    }
+    wsd[c * 4 + 0] = a[0]; wsd[c * 4 + 1] = a[1]; wsd[c * 4 + 2] = a[2]; wsd[c * 4 + 3] = a[3];
+    wsf[c] = mn;
+    wsf[C + c] = mx;
 }
 
 __global__ __launch_bounds__(256) void k_fast_apply(const float* __restrict__ z, int N, int C, int H, int W, float* __restrict__ out,
@@ -410,10 +433,15 @@ extern "C" int mdtile_vae_fast_input(const float* d_z, int N, int C, int H, int 
     MDT_CHECK_ARG(oh > 0 && ow > 0, "mdtile_vae_fast_input: empty estimator input");
     const double sf = (double)tile_size / (double)(H > W ? H : W);
     const float sc = (float)(1.0 / sf);  // torch: scale = 1/scale_factor when a scale_factor is given
+    // workspace: [ per-channel totals: 4 doubles x C | partial doubles 4 x C x FAST_NBLK | totals min/max 2 floats x C | partial floats ]
     double* wsd = (double*)d_ws;
-    float* wsf = (float*)(wsd + 4 * (size_t)C);
+    double* pd = wsd + 4 * (size_t)C;
+    float* wsf = (float*)(pd + 4 * (size_t)C * FAST_NBLK);
+    float* pf = wsf + 2 * (size_t)C;
     hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL(k_fast_stats, dim3(C), dim3(256), 0, s, d_z, N, C, H, W, oh, ow, sc, sc, wsd, wsf);
+    hipLaunchKernelGGL(k_fast_stats, dim3(FAST_NBLK, C), dim3(256), 0, s, d_z, N, C, H, W, oh, ow, sc, sc, pd, pf);
+    MDT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_fast_combine, dim3(cdiv(C, 64)), dim3(64), 0, s, (const double*)pd, (const float*)pf, C, wsd, wsf);
     MDT_LAUNCH_CHECK();
     size_t total = (size_t)N * C * oh * ow;
     hipLaunchKernelGGL(k_fast_apply, dim3(cdiv((long long)total, 256)), dim3(256), 0, s, d_z, N, C, H, W, d_out, oh, ow, sc, sc,
@@ -422,4 +450,6 @@ extern "C" int mdtile_vae_fast_input(const float* d_z, int N, int C, int H, int 
     return MDTILE_OK;
 }
 
-extern "C" size_t mdtile_vae_fast_ws_size(int C) { return (size_t)C * (4 * sizeof(double) + 2 * sizeof(float)); }
+extern "C" size_t mdtile_vae_fast_ws_size(int C) {
+    return (size_t)C * (1 + FAST_NBLK) * (4 * sizeof(double) + 2 * sizeof(float));
+}
