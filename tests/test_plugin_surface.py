@@ -72,3 +72,54 @@ def test_tilediffusion_process_arms_and_restores_hijack(plugin):
     s.process(p2, True, "MultiDiffusion", False, True, 1024, 1024, 96, 96, 48, 4, "None", 2.0, False, 10, 1, 1, 64, False,
               False, False, False, *defaults)
     assert sd_samplers.create_sampler is orig
+
+
+def test_tilediffusion_region_control_hijacks_and_restores_random_tensors(plugin):
+    """Region control arms the per-region noise hijack (upstream :376-383) and reset() puts the host's function back."""
+    import modules.processing as processing
+    sentinel = lambda *a, **k: None   # noqa: E731
+    old = processing.create_random_tensors
+    processing.create_random_tensors = sentinel
+    try:
+        s = plugin.tilediffusion.Script()
+        p = sh.make_processing(2048, 2048)
+        p.extra_generation_params = {}
+        regions = [True, 0.1, 0.1, 0.4, 0.4, "a cat", "", "Background", 0.2, 42] + list(plugin.utils.DEFAULT_BBOX_SETTINGS) * 7
+        s.process(p, True, "MultiDiffusion", False, True, 1024, 1024, 96, 96, 48, 4, "None", 2.0, False, 10, 1, 1, 64, False,
+                  True, True, False, *regions)
+        assert processing.create_random_tensors is not sentinel
+        assert plugin.tilediffusion.Script.create_random_tensors_original_md is sentinel
+        assert "Region 1" in p.extra_generation_params["Tiled Diffusion"]["Region control"]
+        s.postprocess(p, None, True)
+        assert processing.create_random_tensors is sentinel
+        assert not hasattr(plugin.tilediffusion.Script, "create_random_tensors_original_md")
+    finally:
+        processing.create_random_tensors = old
+
+
+def test_tilevae_process_hooks_both_directions_and_restores(plugin):
+    """Script.process replaces encoder.forward AND decoder.forward with VAEHooks (upstream tilevae.py:739-745);
+    disabling or postprocess restores the originals."""
+    from types import SimpleNamespace
+    import torch
+
+    class Net(torch.nn.Module):
+        def forward(self, x):
+            return x
+
+    enc, dec = Net(), Net()
+    enc_fwd, dec_fwd = enc.forward, dec.forward
+    p = SimpleNamespace(sd_model=SimpleNamespace(first_stage_model=SimpleNamespace(encoder=enc, decoder=dec, device="cpu")))
+    s = plugin.tilevae.Script()
+    s.process(p, True, 3072, 256, True, True, True, False)
+    VAEHook = plugin.tilevae.VAEHook
+    assert isinstance(enc.forward, VAEHook) and isinstance(dec.forward, VAEHook)
+    assert (enc.forward.is_decoder, enc.forward.pad, enc.forward.tile_size) == (False, 32, 3072)
+    assert (dec.forward.is_decoder, dec.forward.pad, dec.forward.tile_size) == (True, 11, 256)
+    assert enc.original_forward == enc_fwd and dec.original_forward == dec_fwd
+    s.postprocess(p, None, True)
+    assert enc.forward == enc_fwd and dec.forward == dec_fwd
+    s.process(p, True, 3072, 256, True, True, True, True)
+    assert enc.forward.color_fix and not dec.forward.color_fix          # color_fix is an encoder-only mode (upstream :370)
+    s.process(p, False, 3072, 256, True, True, True, False)              # "disabled": undo a hook left over from a crashed job
+    assert enc.forward == enc_fwd and dec.forward == dec_fwd
