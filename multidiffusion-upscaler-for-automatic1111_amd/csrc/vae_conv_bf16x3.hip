@@ -41,6 +41,7 @@ struct ConvBParams {
     int Hin, Win, up;         // input spatial size; up = 1 for fused nearest-2x
     int ptiles, PX, NCB, NK;  // pixel tiles, tiles per row, cout blocks, 16-channel K-steps
     const float* coef;        // fused pre-activation (GNS kernels): [B][2][Cin] = per-channel scale a, shift s; x' = silu(a x + s)
+    int prio;                 // 1: raise the wave's issue priority (s_setprio 1) while it runs a tap column's MFMAs (MDTILE_CONV_PRIO=1)
 };
 
 constexpr int MAX_GN_CIN = 512;   // the fused pre-activation keeps a[Cin], s[Cin] in LDS
@@ -242,6 +243,7 @@ __global__ __launch_bounds__(512, IB1 ? 4 : 2) void k_conv3x3_bf16x3(const ConvB
                 for (int hl = 0; hl < 2; ++hl) {
                     a[m][hl] = __builtin_bit_cast(bf16x8, wst[((hl * 3 + dx) * MT + wm * 2 + m) * 64 + lane]);
                 }
+            if (P.prio) __builtin_amdgcn_s_setprio(1);
             if (ORD == 2) {
                 bf16x8 bh[NROW], bl[NROW];
 #pragma unroll
@@ -273,6 +275,7 @@ __global__ __launch_bounds__(512, IB1 ? 4 : 2) void k_conv3x3_bf16x3(const ConvB
                     }
                 }
             }
+            if (P.prio) __builtin_amdgcn_s_setprio(0);
         }
 
         if (W3) {
@@ -647,6 +650,8 @@ bool conv_bf16x3_gn_supported(int cout, int cin, int ksize, int up) {
 int conv_bf16x3_launch(const float* d_x, const void* d_w_rec, const float* d_bias, const float* d_res, float* d_y, int B, int cin,
                        int cout, int H, int W, int up, const float* d_coef, hipStream_t s) {
     ConvBParams P;
+    static const int prio = [] { const char* e = getenv("MDTILE_CONV_PRIO"); return e ? atoi(e) : 0; }();
+    P.prio = prio;
     P.coef = d_coef;
     P.x = d_x; P.w = (const u32x4*)d_w_rec; P.bias = d_bias; P.res = d_res; P.y = d_y;
     P.B = B; P.Cin = cin; P.Cout = cout; P.H = H; P.W = W;
