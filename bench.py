@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--slow-vae", action="store_true", help="slow-mode GroupNorm (pooled per norm) instead of fast mode")
     ap.add_argument("--no-vae", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f32-pass", action="store_true", help="skip the strict-fp32 companion decode (parity.rel_err_vs_f32, value_f32)")
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the per-stage split and the HIP-event roofline pass (PMC runs)")
     ap.add_argument("--cpu-vae-latent", type=int, default=88, help="width of the 64-row latent of the CPU VAE sample")
     ap.add_argument("--debug-single-device", action="store_true",
@@ -238,7 +239,8 @@ def main():
                 prof.wrap("blend", blend_bytes, lambda: E.blend(plan, method, [tile_out], N, C, out=blend_out, packed=True, **kw))
         if hook is not None:
             orig_call = E.PackedConv.__call__
-            subpixel = os.environ.get("MDTILE_UPCONV", "") != "direct" and os.environ.get("MDTILE_CONV_MODE", "") != "f32"
+            orig_rec = E.PackedConv.call_rec
+            subpixel = E.get_precision() == E.PRECISION_BF16X3
 
             def timed_call(self, x, residual=None, upsample2x=False, token_major=False, exact=False, pre_gn=None):
                 B, cin, H, W = x.shape
@@ -252,6 +254,17 @@ def main():
                     tag = "upconv_subpixel"
                 return prof.wrap(tag, flops, lambda: orig_call(self, x, residual, upsample2x, token_major, exact, pre_gn))
 
+            def timed_rec(self, x, residual=None, upsample2x=False, want_f32=True, want_rec=False, rec_coef=None):
+                B, cin, H, W = x.shape
+                if upsample2x:
+                    H, W = 2 * H, 2 * W
+                flops = 2.0 * B * H * W * self.cout * cin * 9
+                tag = "conv3x3_wide"
+                if upsample2x:
+                    flops *= 4.0 / 9.0
+                    tag = "upconv_subpixel"
+                return prof.wrap(tag, flops, lambda: orig_rec(self, x, residual, upsample2x, want_f32, want_rec, rec_coef))
+
             orig_attn = E.vae_attn
 
             def timed_attn(q, k, v, scale):
@@ -259,6 +272,7 @@ def main():
                 return prof.wrap("attn", 4.0 * B * T * T * Cc, lambda: orig_attn(q, k, v, scale))
 
             E.PackedConv.__call__ = timed_call
+            E.PackedConv.call_rec = timed_rec
             E.vae_attn = timed_attn
             builtins.print = lambda *a, **k: None
             try:
@@ -266,6 +280,7 @@ def main():
             finally:
                 builtins.print = _print
                 E.PackedConv.__call__ = orig_call
+                E.PackedConv.call_rec = orig_rec
                 E.vae_attn = orig_attn
         agg = prof.summary()
         if "blend" in agg:
@@ -281,7 +296,7 @@ def main():
             ach = work / secs / 1e12
             # which matrix-core path the dominant kernel ran on: 3x3 convs with cin % 16 == 0 and attention use the
             # split-bf16 kernels unless MDTILE_CONV_MODE=f32 / the exact flag is set; 1x1 convs and narrow convs are fp32 MFMA
-            bf16x3 = os.environ.get("MDTILE_CONV_MODE", "") != "f32" and dom in ("conv3x3_wide", "upconv_subpixel", "attn")
+            bf16x3 = E.get_precision() == E.PRECISION_BF16X3 and dom in ("conv3x3_wide", "upconv_subpixel", "attn")
             peak = MFMA_BF16X3_PEAK_TFLOPS if bf16x3 else MFMA_F32_PEAK_TFLOPS
             roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                         "frac": round(ach / peak, 4), "traffic": None, "launches": n,
@@ -294,7 +309,7 @@ def main():
 
     # HBM traffic per launch from a PREVIOUS pair of rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
     # (tools/pmc_summary.py writes the json; the counters cannot be read from inside the process)
-    pmc_path = os.environ.get("MDTILE_PMC_SUMMARY", "")
+    pmc_path = os.environ.get("MDTILE_PMC_SUMMARY", "") or os.path.join(ROOT, "profiles", "pmc_hbm_summary_current.json")
     if rank == 0 and pmc_path and os.path.exists(pmc_path):
         with open(pmc_path) as f:
             pmc = json.load(f)
@@ -305,6 +320,33 @@ def main():
                 if hit:
                     rl["traffic"] = int(sum(h["hbm_bytes_per_launch"] * h["dispatches"] for h in hit) / max(1, sum(h["dispatches"] for h in hit)))
                     rl["traffic_unit"] = "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+                    rl["traffic_source"] = os.path.relpath(pmc_path, ROOT) + " (rocprofv3 --pmc passes of this command; the counters cannot be read from inside the process)"
+
+    # ------------------------------------------------------------------ strict-fp32 companion: same decode on the exact-fp32 MFMA kernels
+    # (untimed region of the headline; its own clock).  `parity.rel_err_vs_f32` = max |bf16x3 - f32| / max |f32| over the whole image.
+    parity = value_f32 = ms_f32 = None
+    if rank == 0 and world == 1 and hook is not None and not args.no_f32_pass and E.get_precision() == E.PRECISION_BF16X3:
+        builtins.print = lambda *a, **k: None
+        try:
+            img = hook(z).float()
+            E.set_precision(E.PRECISION_F32)
+            hook(z)                                  # weights / workspaces of the exact kernels warm
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.evals):
+                blend_eval()
+            img32 = hook(z).float()
+            torch.cuda.synchronize()
+            ms_f32 = (time.perf_counter() - t0) * 1e3
+        finally:
+            E.set_precision(E.PRECISION_BF16X3)
+            builtins.print = _print
+        value_f32 = L * L / (ms_f32 * 1e-3)
+        den = img32.abs().max().item()
+        parity = {"rel_err_vs_f32": float((img - img32).abs().max().item() / den), "rms_err_vs_f32": float(((img - img32).pow(2).mean().sqrt() / den).item()),
+                  "what": "whole 8K image of the timed configuration: default split-bf16 engine vs the engine's exact-fp32 MFMA kernels (mdtile_set_precision), same z and weights",
+                  "tolerance": 1e-3, "oracle_parity": "tests/test_gpu_vae_large.py (tile-256 tiles vs the oracle on torch fp32; tile-64 vs the CPU oracle)"}
+        del img, img32
 
     # ------------------------------------------------------------------ CPU baseline (oracle = port of the reference), rank 0, N=1
     cpu_baseline = None
@@ -365,7 +407,7 @@ def main():
         out = {
             "metric": "latent-px/sec tile-blend+VAE-decode, 8K image", "value": round(value, 1), "unit": "latent-px/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32" if os.environ.get("MDTILE_CONV_MODE", "") == "f32" else "bf16x3+f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32" if E.get_precision() == E.PRECISION_F32 else "bf16x3+f32", "data": "synthetic",
             "config": {"workload": f"SDXL 8192x8192 (latent {L}x{L}): {args.evals} x [tile gather + {'MultiDiffusion' if args.method == 'md' else 'Mixture-of-Diffusers'} "
                                    f"blend, {plan.num_tiles} tiles {plan.tile_w}x{plan.tile_h} overlap {plan.overlap}, N=2,C=4] + "
                                    + ("no VAE" if hook is None else f"tiled VAE decode (tile {args.vae_tile}, {'slow' if args.slow_vae else 'fast'} mode, SD decoder ch=128, random weights)"),
@@ -373,6 +415,8 @@ def main():
                        "vae_tile": None if hook is None else args.vae_tile, "sharding": "none" if world == 1 else f"tile-row bands x{world} + halo exchange; VAE tiles round-robin"},
             "stage_ms": {"blend_eval": round(t_blend_eval * 1e3, 4), "vae_decode": None if t_vae is None else round(t_vae * 1e3, 2)},
             "stage_px_per_s": {"blend_eval": round(L * L / t_blend_eval, 1), "vae_decode": None if t_vae is None else round(L * L / t_vae, 1)},
+            "value_f32": None if value_f32 is None else round(value_f32, 1), "ms_per_step_f32": None if ms_f32 is None else round(ms_f32, 2),
+            "parity": parity,
             "roofline": roofline, "roofline_blend": roofline_blend, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))

@@ -50,6 +50,15 @@ typedef struct mdtile_plan mdtile_plan;
 int mdtile_version(void);
 const char* mdtile_last_error(void);
 
+/* Arithmetic of the matrix-core kernels (convs, attention).  Default MDTILE_PRECISION_BF16X3: every fp32 factor is split into two
+ * bf16 halves (16 significand bits), three bf16 MFMAs per product, fp32 accumulation (~1e-5 relative to fp32 end to end; the stated
+ * tolerance of the path is 1e-3).  MDTILE_PRECISION_F32: exact-fp32 MFMA kernels everywhere (bit-comparable to an fp32 fmaf chain),
+ * ~4x slower.  Process-wide; env MDTILE_CONV_MODE=f32 / MDTILE_ATTN_MODE=f32 preset it. */
+#define MDTILE_PRECISION_BF16X3 0
+#define MDTILE_PRECISION_F32 1
+int mdtile_set_precision(int mode);
+int mdtile_get_precision(void);
+
 /* ----------------------------------------------------------------------------------------------------------
  * Grid planning (host integers only).
  * Replaces split_bboxes (tile_utils/utils.py:160-177) + init_grid_bbox (tile_methods/abstractdiffusion.py:173-186):
@@ -219,6 +228,28 @@ int mdtile_gn_coeffs(const float* d_mean, const float* d_var, const float* d_gam
 int mdtile_conv2d_gn_supported(int cout, int cin, int ksize, int flags, int out_layout);
 int mdtile_conv2d_gn(const float* d_x, const float* d_coef, const float* d_w_packed, const float* d_bias, const float* d_residual,
                      float* d_y, int B, int cin, int cout, int H, int W, int ksize, int flags, mdtile_stream_t stream);
+
+/* Record-image conv path (fast mode: every GroupNorm's statistics are frozen before the tiles run, tilevae.py:464-505, 542-563).
+ * A "record image" of an activation [B, C, H, W] (C % 32 == 0) is its split-bf16 form in MFMA fragment order with a
+ * 1-pixel zero border:  rec[b][hl][C/8][H+2][W+2] x 16 bytes, hl = 0: bf16(x), hl = 1: bf16(x - hi); plane p = 2*kstep + kg
+ * holds channels 32*(kstep>>1) + 16*(kstep&1) + 4*kg + (j&3) + 8*(j>>2), j = 0..7  -- 4 bytes per element, like fp32.
+ * The PRODUCER applies the following norm's (a, s) + SiLU (custom_group_norm + inplace_nonlinearity, tilevae.py:218-245,
+ * 102-104) and splits; the consuming conv stages its input by DMA only.
+ *   mdtile_rec_size            : bytes of the record image of [B, C, H, W]
+ *   mdtile_rec_from_f32        : rec = split(silu(a x + s)) (d_coef = mdtile_gn_coeffs output [B][2][C]) or split(x) (d_coef NULL)
+ *   mdtile_rec_to_f32          : x = hi + lo (inspection / tests)
+ *   mdtile_conv2d_rec_supported: 1 when the record kernels take the shape (3x3, cin % 32 == 0, cout % 128 == 0)
+ *   mdtile_conv2d_rec          : y = conv3x3(x_rec) + bias (+ residual), written as fp32 NCHW (d_y, may be NULL) and / or as the
+ *                                record image d_y_rec = split(silu(a y + s)) (d_y_coef [B][2][cout]) or split(y) (d_y_coef NULL);
+ *                                MDTILE_CONV_UPSAMPLE2X: x_rec is the HALF-size input of the fused nearest-2x upsample conv
+ *                                (ldm Upsample, tilevae.py:139-153).  H, W = output size.  d_w_packed: mdtile_conv_pack(ksize 3). */
+size_t mdtile_rec_size(int B, int C, int H, int W);
+int mdtile_rec_from_f32(const float* d_x, const float* d_coef, void* d_rec, int B, int C, int H, int W, mdtile_stream_t stream);
+int mdtile_rec_to_f32(const void* d_rec, float* d_x, int B, int C, int H, int W, mdtile_stream_t stream);
+int mdtile_conv2d_rec_supported(int cout, int cin, int ksize, int flags);
+int mdtile_conv2d_rec(const void* d_x_rec, const float* d_w_packed, const float* d_bias, const float* d_residual, float* d_y,
+                      void* d_y_rec, const float* d_y_coef, int B, int cin, int cout, int H, int W, int flags,
+                      mdtile_stream_t stream);
 
 /* Row-band pieces of get_var_mean (tilevae.py:207-215) for an activation that is split by rows across GPUs (sequence-parallel
  * fast-mode estimator): every plane holds plane_stride floats of which [offset, offset+len) are this rank's own rows.

@@ -14,6 +14,8 @@
 namespace mdt {
 
 void set_error(const char* fmt, ...);
+bool conv_strict_f32();   // mdtile_set_precision / MDTILE_CONV_MODE=f32: every conv on the exact-fp32 MFMA kernels
+bool attn_strict_f32();   // ... / MDTILE_ATTN_MODE=f32: attention on the exact-fp32 kernel
 int plan_upload(const struct ::mdtile_plan* plan);  // mirror the plan's lookup tables to the current device (idempotent)
 
 #define MDT_CHECK_ARG(cond, ...)           \

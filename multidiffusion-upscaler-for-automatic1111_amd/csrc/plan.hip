@@ -17,6 +17,26 @@ void set_error(const char* fmt, ...) {
 }  // namespace mdt
 
 extern "C" int mdtile_version(void) { return MDTILE_VERSION; }
+
+// ---- arithmetic of the matrix-core kernels: split-bf16 ("bf16x3") by default, exact fp32 MFMA on request ----
+namespace mdt {
+static int g_precision = [] {
+    const char* c = getenv("MDTILE_CONV_MODE");
+    const char* a = getenv("MDTILE_ATTN_MODE");
+    return ((c && strcmp(c, "f32") == 0) ? 1 : 0) | ((a && strcmp(a, "f32") == 0) ? 2 : 0);
+}();
+bool conv_strict_f32() { return (g_precision & 1) != 0; }
+bool attn_strict_f32() { return (g_precision & 2) != 0; }
+}  // namespace mdt
+extern "C" int mdtile_set_precision(int mode) {
+    if (mode != MDTILE_PRECISION_BF16X3 && mode != MDTILE_PRECISION_F32) {
+        mdt::set_error("mdtile_set_precision: unknown mode %d", mode);
+        return MDTILE_E_ARG;
+    }
+    mdt::g_precision = mode == MDTILE_PRECISION_F32 ? 3 : 0;
+    return MDTILE_OK;
+}
+extern "C" int mdtile_get_precision(void) { return mdt::g_precision == 3 ? MDTILE_PRECISION_F32 : MDTILE_PRECISION_BF16X3; }
 extern "C" const char* mdtile_last_error(void) { return mdt::g_err; }
 
 // 1-D origins: count = ceil((extent-ov)/(tile-ov)); step is a double; origin = min(trunc(i*step), extent-tile).

@@ -213,10 +213,7 @@ int attn_bf16x3_launch(const float* d_q, const float* d_k, const float* d_v_tok,
                        void* d_ws, hipStream_t s);
 }  // namespace mdt
 
-static bool attn_force_f32() {
-    static const bool f = [] { const char* e = getenv("MDTILE_ATTN_MODE"); return e && strcmp(e, "f32") == 0; }();
-    return f;
-}
+static bool attn_force_f32() { return attn_strict_f32(); }
 
 // the flash formulation keeps every intermediate on chip; the split-bf16 path needs room for the fragment-order
 // bf16 hi/lo images of q, k and v

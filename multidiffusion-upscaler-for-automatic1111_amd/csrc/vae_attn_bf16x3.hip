@@ -470,18 +470,10 @@ int attn_bf16x3_launch(const float* d_q, const float* d_k, const float* d_v_tok,
     MDT_LAUNCH_CHECK();
     const int nq8 = (Tq128 / BQ + 7) / 8 * 8;
     dim3 grid(nq8 * ns, B), block(512);
-    // slab transport: direct global -> LDS DMA (default) or global -> VGPR -> ds_write (MDTILE_ATTN_DMA=0)
-    static const bool dma = [] { const char* e = getenv("MDTILE_ATTN_DMA"); return !(e && strcmp(e, "0") == 0); }();
 #define MDT_ATTN_LAUNCH(CC, DD) hipLaunchKernelGGL((k_attn_bf16x3<CC, DD>), grid, block, 0, s, Qr, Kr, Vr, d_out, Tq, Tq128, Tk, Tk128, scale, ns, part, pstat)
-    if (dma) {
-        if (C == 512) MDT_ATTN_LAUNCH(512, true);
-        else if (C == 256) MDT_ATTN_LAUNCH(256, true);
-        else MDT_ATTN_LAUNCH(128, true);
-    } else {
-        if (C == 512) MDT_ATTN_LAUNCH(512, false);
-        else if (C == 256) MDT_ATTN_LAUNCH(256, false);
-        else MDT_ATTN_LAUNCH(128, false);
-    }
+    if (C == 512) MDT_ATTN_LAUNCH(512, true);
+    else if (C == 256) MDT_ATTN_LAUNCH(256, true);
+    else MDT_ATTN_LAUNCH(128, true);
 #undef MDT_ATTN_LAUNCH
     MDT_LAUNCH_CHECK();
     if (ns > 1) {

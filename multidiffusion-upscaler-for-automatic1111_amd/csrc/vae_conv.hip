@@ -232,6 +232,13 @@ int conv_bf16x3_pack(const float* d_w_oihw, void* d_out, int cout, int cin, hipS
 bool conv_bf16x3_gn_supported(int cout, int cin, int ksize, int up);
 int conv_bf16x3_launch(const float* d_x, const void* d_w_rec, const float* d_bias, const float* d_res, float* d_y, int B, int cin,
                        int cout, int H, int W, int up, const float* d_coef, hipStream_t s);
+// vae_conv_rec.hip
+bool conv_rec_supported(int cout, int cin, int ksize);
+size_t rec_image_bytes(int B, int C, int H, int W);
+int rec_from_f32_launch(const float* d_x, const float* d_coef, void* d_rec, int B, int C, int H, int W, hipStream_t s);
+int rec_to_f32_launch(const void* d_rec, float* d_x, int B, int C, int H, int W, hipStream_t s);
+int conv_rec_launch(const void* d_xrec, const void* d_w_rec, const float* d_bias, const float* d_res, float* d_y32, void* d_yrec,
+                    const float* d_ycoef, int B, int cin, int cout, int H, int W, int up, hipStream_t s);
 // vae_conv1x1_bf16x3.hip
 bool conv1x1_bf16x3_eligible(int cout, int cin);
 size_t conv1x1_bf16x3_packed_floats(int cout, int cin);
@@ -277,12 +284,11 @@ extern "C" int mdtile_conv2d(const float* d_x, const float* d_w_packed, const fl
     P.Hin = up ? H / 2 : H; P.Win = up ? W / 2 : W; P.up = up;
     hipStream_t s = as_stream(stream);
     // split-bf16 matrix-core path (16/3 x the fp32-MFMA rate, ~1e-5 relative): default for the 3x3 convs it covers
-    static const bool force_f32 = [] { const char* e = getenv("MDTILE_CONV_MODE"); return e && strcmp(e, "f32") == 0; }();
+    const bool force_f32 = conv_strict_f32();
     if (!force_f32 && !(flags & MDTILE_CONV_EXACT_F32) && out_layout == 0 && conv_bf16x3_eligible(cout, cin, ksize))
         return conv_bf16x3_launch(d_x, d_w_packed + f32_packed_floats(cout, cin, ksize), d_bias, d_residual, d_y, B, cin, cout, H, W, up, nullptr, s);
-    // 1x1 convs (nin_shortcut, q / k / proj_out): split-bf16 kernel over the flat pixel run; MDTILE_CONV1X1=f32 keeps the exact kernel
-    static const bool c1_f32 = [] { const char* e = getenv("MDTILE_CONV1X1"); return e && strcmp(e, "f32") == 0; }();
-    if (ksize == 1 && !up && !force_f32 && !c1_f32 && !(flags & MDTILE_CONV_EXACT_F32) && out_layout == 0 && conv1x1_bf16x3_eligible(cout, cin))
+    // 1x1 convs (nin_shortcut, q / k / proj_out): split-bf16 kernel over the flat pixel run
+    if (ksize == 1 && !up && !force_f32 && !(flags & MDTILE_CONV_EXACT_F32) && out_layout == 0 && conv1x1_bf16x3_eligible(cout, cin))
         return conv1x1_bf16x3_launch(d_x, d_w_packed + f32_packed_floats(cout, cin, ksize), d_bias, d_residual, d_y, B, cin, cout,
                                      (size_t)H * W, s);
     const bool wide = P.CoutP > 64;
@@ -294,10 +300,7 @@ extern "C" int mdtile_conv2d(const float* d_x, const float* d_w_packed, const fl
     return launch_conv<1, 16, 4, 1, 2, 1>(P, out_layout, s);
 }
 
-static bool conv_force_f32() {
-    static const bool v = [] { const char* e = getenv("MDTILE_CONV_MODE"); return e && strcmp(e, "f32") == 0; }();
-    return v;
-}
+static bool conv_force_f32() { return conv_strict_f32(); }
 
 extern "C" int mdtile_conv2d_gn_supported(int cout, int cin, int ksize, int flags, int out_layout) {
     if (conv_force_f32() || (flags & MDTILE_CONV_EXACT_F32) || out_layout != 0) return 0;
@@ -313,6 +316,48 @@ extern "C" int mdtile_conv2d_gn(const float* d_x, const float* d_coef, const flo
     MDT_CHECK_ARG((size_t)H * W < (1u << 24), "mdtile_conv2d_gn: input plane too large for the staging map");
     return conv_bf16x3_launch(d_x, d_w_packed + f32_packed_floats(cout, cin, ksize), d_bias, d_residual, d_y, B, cin, cout, H, W, 0, d_coef,
                               as_stream(stream));
+}
+
+// ---- record-image conv path (vae_conv_rec.hip) ----------------------------------------------------------------------
+extern "C" size_t mdtile_rec_size(int B, int C, int H, int W) {
+    if (B <= 0 || C <= 0 || C % 32 != 0 || H <= 0 || W <= 0) return 0;
+    return rec_image_bytes(B, C, H, W);
+}
+
+static bool rec_image_ok(int B, int C, int H, int W) {
+    // per-lane DMA offsets are 32-bit BYTE offsets inside one pair of planes; record indices of a whole image stay below 2^32
+    return B > 0 && C > 0 && C % 32 == 0 && H > 0 && W > 0 && H + 2 <= 65535 && (size_t)B * (C / 8) <= 65535 &&
+           2 * (size_t)(H + 2) * (W + 2) * 16 < ((size_t)1 << 32);
+}
+
+extern "C" int mdtile_rec_from_f32(const float* d_x, const float* d_coef, void* d_rec, int B, int C, int H, int W, mdtile_stream_t stream) {
+    MDT_CHECK_ARG(d_x && d_rec, "mdtile_rec_from_f32: null argument");
+    MDT_CHECK_ARG(rec_image_ok(B, C, H, W), "mdtile_rec_from_f32: unsupported shape B=%d C=%d H=%d W=%d (C %% 32 == 0 required)", B, C, H, W);
+    return rec_from_f32_launch(d_x, d_coef, d_rec, B, C, H, W, as_stream(stream));
+}
+
+extern "C" int mdtile_rec_to_f32(const void* d_rec, float* d_x, int B, int C, int H, int W, mdtile_stream_t stream) {
+    MDT_CHECK_ARG(d_x && d_rec, "mdtile_rec_to_f32: null argument");
+    MDT_CHECK_ARG(rec_image_ok(B, C, H, W), "mdtile_rec_to_f32: unsupported shape B=%d C=%d H=%d W=%d", B, C, H, W);
+    return rec_to_f32_launch(d_rec, d_x, B, C, H, W, as_stream(stream));
+}
+
+extern "C" int mdtile_conv2d_rec_supported(int cout, int cin, int ksize, int flags) {
+    if (conv_force_f32() || (flags & MDTILE_CONV_EXACT_F32)) return 0;
+    return conv_rec_supported(cout, cin, ksize) ? 1 : 0;
+}
+
+extern "C" int mdtile_conv2d_rec(const void* d_x_rec, const float* d_w_packed, const float* d_bias, const float* d_residual, float* d_y,
+                                 void* d_y_rec, const float* d_y_coef, int B, int cin, int cout, int H, int W, int flags,
+                                 mdtile_stream_t stream) {
+    MDT_CHECK_ARG(d_x_rec && d_w_packed && (d_y || d_y_rec), "mdtile_conv2d_rec: null argument (one of d_y / d_y_rec is required)");
+    MDT_CHECK_ARG(mdtile_conv2d_rec_supported(cout, cin, 3, flags), "mdtile_conv2d_rec: no record kernel for cout=%d cin=%d flags=%d", cout, cin, flags);
+    const int up = (flags & MDTILE_CONV_UPSAMPLE2X) ? 1 : 0;
+    MDT_CHECK_ARG(!up || (H % 2 == 0 && W % 2 == 0), "mdtile_conv2d_rec: upsample2x needs even output size, got %dx%d", H, W);
+    MDT_CHECK_ARG(rec_image_ok(B, cin, up ? H / 2 : H, up ? W / 2 : W) && rec_image_ok(B, cout, H, W),
+                  "mdtile_conv2d_rec: unsupported shape B=%d cin=%d cout=%d H=%d W=%d", B, cin, cout, H, W);
+    return conv_rec_launch(d_x_rec, d_w_packed + f32_packed_floats(cout, cin, 3), d_bias, d_residual, d_y, d_y_rec, d_y_coef, B, cin, cout,
+                           H, W, up, as_stream(stream));
 }
 
 // ldm Downsample: y = conv3x3_stride2(pad(x, right 1, bottom 1)); output (Hin - 2) / 2 + 1 rows (likewise columns).

@@ -38,10 +38,10 @@ struct ConvBParams {
     const float* res;    // residual [B, Cout, H, W] or null
     float* y;            // [B, Cout, H, W]
     int B, Cin, Cout, H, W;   // H, W: OUTPUT spatial size
-    int Hin, Win, up;         // input spatial size; up = 1 for fused nearest-2x
+    int Hin, Win, up;         // input spatial size; up = 1: sub-pixel upsample kernel (output = 2x input)
     int ptiles, PX, NCB, NK;  // pixel tiles, tiles per row, cout blocks, 16-channel K-steps
     const float* coef;        // fused pre-activation (GNS kernels): [B][2][Cin] = per-channel scale a, shift s; x' = silu(a x + s)
-    int prio;                 // 1: raise the wave's issue priority (s_setprio 1) while it runs a tap column's MFMAs (MDTILE_CONV_PRIO=1)
+    int perm;                 // channel order inside a K-step, see kstep_c0 / kstep_cj
 };
 
 constexpr int MAX_GN_CIN = 512;   // the fused pre-activation keeps a[Cin], s[Cin] in LDS
@@ -60,28 +60,26 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo
     lo = __builtin_bit_cast(u32x4, l);
 }
 
+// Channel order inside a 16-channel K-step.  perm = 1 (cin % 32 == 0): K index (kg, j) of K-step k is channel
+//     32*(k>>1) + 16*(k&1) + 4*kg + (j&3) + 8*(j>>2)
+// = the channels one lane of a 32x32 MFMA accumulator tile owns, which is the order the record-image conv family
+// (vae_conv_rec.hip) stores activations in; ONE packed weight image then serves both families.  perm = 0: k*16 + kg*8 + j.
+__device__ __host__ __forceinline__ int kstep_c0(int k, int kg, int perm) { return perm ? 32 * (k >> 1) + 16 * (k & 1) + 4 * kg : k * 16 + kg * 8; }
+__device__ __host__ __forceinline__ int kstep_cj(int j, int perm) { return perm ? (j & 3) + 8 * (j >> 2) : j; }
+
 // GNS = true: the fixed-statistics GroupNorm + SiLU that precedes conv1 / conv2 in every resblock (custom_group_norm +
 // inplace_nonlinearity, scripts/tilevae.py:218-245, 102-104) is applied to the input while it is staged:
 // x' = silu(fma(x, a[c], s[c])) with a = gamma * rstd, s = beta - mean * a (mdtile_gn_coeffs) -- the normalised activation is
 // never written to HBM (1R + 1W of every pre-conv activation saved).  Zero padding applies to x' (mask after the transform).
-// WDMA = true: the weight chunks (already in fragment order) go global -> LDS by DMA (global_load_lds_dwordx4) instead of
-// through VGPRs + ds_write_b128; same two-stage schedule (issued at the start of a phase, drained before its closing barrier).
-// IB1 = true: ONE input stage instead of two (an extra barrier before the stage is overwritten, once per K-step) and a
-// 128-VGPR budget: 70.8 KB LDS + 128 registers let TWO blocks share a CU (4 waves per SIMD) -- the barrier / LDS-latency
-// stalls of one block are covered by the other block's MFMAs.  Only with MT = 4, TH_ = 8, WDMA.
-// W3 = true (needs WDMA, MT = 4): THREE weight stages -- the DMA of a weight chunk is issued two phases before its use (one
-// phase for one chunk in three), so the L2 / Infinity-Cache latency of the weight stream is covered by a whole extra phase of
-// MFMAs instead of being waited for at every phase boundary.  The loop then uses a raw s_barrier with counted
-// s_waitcnt vmcnt(3) (= "all but this thread's 3 youngest DMA ops have landed"): __syncthreads() would drain every DMA.
-// Counting only the DMA ops this code issues itself keeps the waits correct wherever the compiler places the ordinary
-// (input) loads: additional younger loads can only make vmcnt(3) wait for more, never for less.
-// ORD: order of the three MFMAs (w_lo x_hi, w_hi x_lo, w_hi x_hi) that feed one accumulator, relative to the other accumulators.
-//   0: as hipcc schedules the straightforward loop nest (it alternates TWO accumulators: every MFMA waits on the one before last)
-//   1: the three MFMAs of an accumulator pinned back to back (scheduling barriers that only MFMAs may not cross)
-//   2: term-major over all accumulators of a tap column (a dependent MFMA is >= 4 MFMAs away); needs every input fragment live
-template <int MT, int TH_, bool GNS, bool WDMA, bool IB1 = false, bool W3 = false, int ORD = 0>  // MT: 32-cout tiles per block, 4 (BM = 128) or 2 (BM = 64); TH_: pixel rows per block, 8 or 16
-__global__ __launch_bounds__(512, IB1 ? 4 : 2) void k_conv3x3_bf16x3(const ConvBParams P) {
-    static_assert(!W3 || (WDMA && MT == 4 && !IB1), "the 3-stage weight ring is built for the DMA path of the 128-cout blocks");
+// Two block shapes (every other variant was measured and dropped):
+//   MT = 4 (128 couts): weights by LDS-DMA (already in fragment order), ONE input stage (an extra barrier before it is
+//           overwritten, once per K-step), 124 VGPR + 71 KB LDS -> TWO blocks per CU (4 waves per SIMD); MFMAs issued
+//           term-major across the accumulators of a tap column (a dependent MFMA is >= 4 MFMAs away)
+//   MT = 2 (64 couts, small decoders): weights through VGPRs, two input stages
+template <int MT, bool GNS>
+__global__ __launch_bounds__(512, MT == 4 ? 4 : 2) void k_conv3x3_bf16x3(const ConvBParams P) {
+    constexpr int TH_ = 8;
+    constexpr bool WDMA = MT == 4, IB1 = MT == 4, TERM_MAJOR = MT == 4;
     constexpr int BM = MT * 32;
     constexpr int WAVES_M = MT / 2, WAVES_R = 8 / WAVES_M, NROW = TH_ / WAVES_R;
     constexpr int ROWS_ = TH_ + 2, IN_REC_ = 2 * ROWS_ * COLS;   // halo tile records per hl per stage
@@ -89,7 +87,7 @@ __global__ __launch_bounds__(512, IB1 ? 4 : 2) void k_conv3x3_bf16x3(const ConvB
     constexpr int W_REC = 2 * 3 * MT * 64;              // records per weight chunk (hi block then lo block)
     constexpr int NWREG = (W_REC + 511) / 512;          // 3 (MT = 4) or 2 (MT = 2, half of the threads on the 2nd)
     // LDS (16-byte records): input [2 stages][hl][IN_REC_], weights [2 stages][W_REC]
-    constexpr int IN_STAGE = 2 * IN_REC_, NIST = IB1 ? 1 : 2, WST = W3 ? 3 : 2;
+    constexpr int IN_STAGE = 2 * IN_REC_, NIST = IB1 ? 1 : 2, WST = 2;
     __shared__ u32x4 smem[NIST * IN_STAGE + WST * W_REC];
     __shared__ float4 coef_l[GNS ? 2 * MAX_GN_CIN / 4 : 1];   // a[0..Cin) at 0, s[0..Cin) at MAX_GN_CIN
     u32x4* const in_l = smem;
@@ -130,9 +128,8 @@ __global__ __launch_bounds__(512, IB1 ? 4 : 2) void k_conv3x3_bf16x3(const ConvB
         const int r = p / COLS, c = p - r * COLS;
         const int gy = y0 + r - 1, gx = x0 + c - 1;
         const bool inside = gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
-        const int sy = P.up ? gy >> 1 : gy, sx = P.up ? gx >> 1 : gx;
         scg[i] = cg;
-        soff[i] = inside ? sy * P.Win + sx : 0;
+        soff[i] = inside ? gy * P.Win + gx : 0;
         smask[i] = inside ? 1.0f : 0.0f;
     }
     float rin[NPASS][8];
@@ -142,9 +139,9 @@ __global__ __launch_bounds__(512, IB1 ? 4 : 2) void k_conv3x3_bf16x3(const ConvB
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
             if (wave_u * 64 + 512 * i < IN_REC_) {               // whole waves past the end of the record list skip the pass
-                const float* src = xb + (size_t)(k * 16 + scg[i] * 8) * HWin + soff[i];
+                const float* src = xb + (size_t)kstep_c0(k, scg[i], P.perm) * HWin + soff[i];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) rin[i][j] = src[(size_t)j * HWin];
+                for (int j = 0; j < 8; ++j) rin[i][j] = src[(size_t)kstep_cj(j, P.perm) * HWin];
             }
         }
     };
@@ -155,8 +152,8 @@ __global__ __launch_bounds__(512, IB1 ? 4 : 2) void k_conv3x3_bf16x3(const ConvB
             if (wave_u * 64 + 512 * i < IN_REC_) {
                 float v[8];
                 if (GNS) {
-                    const int c4 = (k * 16 + scg[i] * 8) >> 2;
-                    const float4 a0 = coef_l[c4], a1 = coef_l[c4 + 1], s0 = coef_l[MAX_GN_CIN / 4 + c4], s1 = coef_l[MAX_GN_CIN / 4 + c4 + 1];
+                    const int c4 = kstep_c0(k, scg[i], P.perm) >> 2, c4b = c4 + (P.perm ? 2 : 1);   // channels j = 4..7 sit 8 (perm) or 4 further
+                    const float4 a0 = coef_l[c4], a1 = coef_l[c4b], s0 = coef_l[MAX_GN_CIN / 4 + c4], s1 = coef_l[MAX_GN_CIN / 4 + c4b];
                     const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
                     const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
 #pragma unroll
@@ -213,24 +210,14 @@ __global__ __launch_bounds__(512, IB1 ? 4 : 2) void k_conv3x3_bf16x3(const ConvB
     const int nph = P.NK * 3;
     load_input(0);
     load_weights(0);
-    if (W3 && nph > 1) load_weights(1);
     store_input(0, 0);
-    store_weights(0);                      // (DMA: vmcnt(0) -- chunks 0 and 1 have landed)
-    if (W3 && P.NK > 1) load_input(1);     // W3 issues the input loads of K-step k+2 at the END of (k, dy = 2), see below
+    store_weights(0);
     __syncthreads();
 
     for (int ph = 0; ph < nph; ++ph) {
         const int k = ph / 3, dy = ph - 3 * k;
-        if (W3) {
-            // chunk ph+2 goes out now (at dy = 2: after this phase's input store, below); its stage held chunk ph-1, which
-            // every wave finished reading before the barrier that closed phase ph-1
-            asm volatile("" ::: "memory");
-            if (dy != 2 && ph + 2 < nph) load_weights(ph + 2);
-            asm volatile("" ::: "memory");
-        } else {
-            if (dy == 0 && k + 1 < P.NK) load_input(k + 1);
-            if (ph + 1 < nph) load_weights(ph + 1);
-        }
+        if (dy == 0 && k + 1 < P.NK) load_input(k + 1);
+        if (ph + 1 < nph) load_weights(ph + 1);
 
         const u32x4* wst = w_l + (ph % WST) * W_REC;
         const u32x4* ist = in_l + (IB1 ? 0 : (k & 1)) * IN_STAGE;
@@ -243,8 +230,7 @@ __global__ __launch_bounds__(512, IB1 ? 4 : 2) void k_conv3x3_bf16x3(const ConvB
                 for (int hl = 0; hl < 2; ++hl) {
                     a[m][hl] = __builtin_bit_cast(bf16x8, wst[((hl * 3 + dx) * MT + wm * 2 + m) * 64 + lane]);
                 }
-            if (P.prio) __builtin_amdgcn_s_setprio(1);
-            if (ORD == 2) {
+            if (TERM_MAJOR) {
                 bf16x8 bh[NROW], bl[NROW];
 #pragma unroll
                 for (int n = 0; n < NROW; ++n) {
@@ -271,41 +257,17 @@ __global__ __launch_bounds__(512, IB1 ? 4 : 2) void k_conv3x3_bf16x3(const ConvB
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], bh, acc[m][n], 0, 0, 0);   // w_lo * x_hi
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], bl, acc[m][n], 0, 0, 0);   // w_hi * x_lo
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], bh, acc[m][n], 0, 0, 0);   // w_hi * x_hi
-                        if (ORD == 1) __builtin_amdgcn_sched_barrier(0x07F7);   // MFMAs stay put: the triple issues back to back
                     }
                 }
             }
-            if (P.prio) __builtin_amdgcn_s_setprio(0);
         }
 
-        if (W3) {
-            // chunk ph+1 must have landed.  Younger DMA ops of this thread: the 3 of chunk ph+2 when it was issued at the top of
-            // this phase (dy != 2 and it exists); none otherwise.
-            asm volatile("" ::: "memory");
-            if (ph + 1 < nph) {
-                if (dy != 2 && ph + 2 < nph) __builtin_amdgcn_s_waitcnt(0x0F73);   // vmcnt(3)
-                else __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0)
-            }
-            if (dy == 2 && k + 1 < P.NK) {
-                store_input((k + 1) & 1, k + 1);
-                // the registers are free again: fetch K-step k+2 now (three phases before it is stored).  hipcc drains vmcnt
-                // before ordinary loads while LDS-DMA is in flight; here nothing is in flight (vmcnt(0) just above).
-                if (k + 2 < P.NK) load_input(k + 2);
-            }
-            asm volatile("" ::: "memory");
-            if (dy == 2 && ph + 2 < nph) load_weights(ph + 2);
-            __builtin_amdgcn_s_waitcnt(0xC07F);                                    // lgkmcnt(0): this wave's LDS stores are done
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-        } else {
-            if (ph + 1 < nph) store_weights((ph + 1) & 1);
-            if (dy == 2 && k + 1 < P.NK) {
-                if (IB1) __syncthreads();      // single input stage: every wave must be done reading K-step k before it is overwritten
-                store_input(IB1 ? 0 : ((k + 1) & 1), k + 1);
-            }
-            __syncthreads();
+        if (ph + 1 < nph) store_weights((ph + 1) & 1);
+        if (dy == 2 && k + 1 < P.NK) {
+            if (IB1) __syncthreads();      // single input stage: every wave must be done reading K-step k before it is overwritten
+            store_input(IB1 ? 0 : ((k + 1) & 1), k + 1);
         }
+        __syncthreads();
     }
 
     // ---- epilogue: + bias (+ residual), store NCHW.  C/D layout of a 32x32 MFMA: col = lane & 31, row = (q&3) + 8*(q>>2) + 4*(lane>>5)
@@ -344,7 +306,7 @@ __global__ __launch_bounds__(512, IB1 ? 4 : 2) void k_conv3x3_bf16x3(const ConvB
 
 // OIHW fp32 -> records [cb][k][dy][hl][dx][mt][lane] of 8 bf16:  cout = cb*BM + mt*32 + (lane & 31),
 // cin = k*16 + (lane >> 5)*8 + j,  tap = (dy, dx);  hl = 0: bf16(w), hl = 1: bf16(w - hi).  Zero outside [Cout) x [Cin).
-__global__ void k_conv_pack_bf16x3(const float* __restrict__ w, u32x4* __restrict__ out, int Cout, int Cin, int MT, int NCB, int NK) {
+__global__ void k_conv_pack_bf16x3(const float* __restrict__ w, u32x4* __restrict__ out, int Cout, int Cin, int MT, int NCB, int NK, int perm) {
     const size_t n = (size_t)NCB * NK * 3 * 2 * 3 * MT * 64;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -360,7 +322,7 @@ __global__ void k_conv_pack_bf16x3(const float* __restrict__ w, u32x4* __restric
     bf16x8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int ci = k * 16 + (lane >> 5) * 8 + j;
+        const int ci = kstep_c0(k, lane >> 5, perm) + kstep_cj(j, perm);
         const float v = (co < Cout && ci < Cin) ? w[(((size_t)co * Cin + ci) * 3 + dy) * 3 + dx] : 0.0f;
         const __bf16 h = (__bf16)v;
         o[j] = hl == 0 ? h : (__bf16)(v - (float)h);
@@ -431,14 +393,14 @@ __global__ __launch_bounds__(512) void k_upconv_bf16x3(const ConvBParams P) {
 
     auto load_input = [&](int k) {
         {
-            const float* src = xb + (size_t)(k * 16 + scg[0] * 8) * HWin + soff[0];
+            const float* src = xb + (size_t)kstep_c0(k, scg[0], P.perm) * HWin + soff[0];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) rin[0][j] = src[(size_t)j * HWin];
+            for (int j = 0; j < 8; ++j) rin[0][j] = src[(size_t)kstep_cj(j, P.perm) * HWin];
         }
         if (has_rec1) {
-            const float* src = xb + (size_t)(k * 16 + scg[1] * 8) * HWin + soff[1];
+            const float* src = xb + (size_t)kstep_c0(k, scg[1], P.perm) * HWin + soff[1];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) rin[1][j] = src[(size_t)j * HWin];
+            for (int j = 0; j < 8; ++j) rin[1][j] = src[(size_t)kstep_cj(j, P.perm) * HWin];
         }
     };
     auto store_input = [&](int stage) {
@@ -572,7 +534,7 @@ __global__ __launch_bounds__(512) void k_upconv_bf16x3(const ConvBParams P) {
 // OIHW fp32 -> merged-tap records [a][cb][k][u][hl][b][v][mt][lane] of 8 bf16 (see k_upconv_bf16x3): the taps of a row
 // parity a / tap u are dy in {0} | {1,2} (a = 0) or {0,1} | {2} (a = 1); columns alike.  The merged weight is the fp32 sum
 // in (dy, dx) order.
-__global__ void k_upconv_pack_bf16x3(const float* __restrict__ w, u32x4* __restrict__ out, int Cout, int Cin, int MT, int NCB, int NK) {
+__global__ void k_upconv_pack_bf16x3(const float* __restrict__ w, u32x4* __restrict__ out, int Cout, int Cin, int MT, int NCB, int NK, int perm) {
     const size_t n = (size_t)2 * NCB * NK * 2 * 2 * 2 * 2 * MT * 64;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -593,7 +555,7 @@ __global__ void k_upconv_pack_bf16x3(const float* __restrict__ w, u32x4* __restr
     bf16x8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int ci = k * 16 + (lane >> 5) * 8 + j;
+        const int ci = kstep_c0(k, lane >> 5, perm) + kstep_cj(j, perm);
         float val = 0.0f;
         if (co < Cout && ci < Cin)
             for (int dy = dy_lo; dy < dy_hi; ++dy)
@@ -612,15 +574,13 @@ namespace mdt {
 
 // shapes the split-bf16 3x3 kernel takes; everything else stays on the exact-fp32 kernel
 bool conv_bf16x3_eligible(int cout, int cin, int ksize) { return ksize == 3 && cin % 16 == 0 && cout >= 32; }
-// cout tiles per block: 128-cout blocks (1 block / CU) for wide convs; MDTILE_CONV_MT=2 forces 64-cout blocks (2 blocks / CU:
-// 4 waves per SIMD, each block's barrier stalls overlap the other's MFMAs) -- affects packing AND launch, set before first use
-static int conv_bf16x3_mt(int cout) {
-    static const int forced = [] { const char* e = getenv("MDTILE_CONV_MT"); return e ? atoi(e) : 0; }();
-    return (forced == 2 || cout <= 64) ? 2 : 4;
-}
+// cout tiles per block: 128-cout blocks for the wide convs, 64-cout blocks for the small decoders' narrow ones
+static int conv_bf16x3_mt(int cout) { return cout <= 64 ? 2 : 4; }
+// K-step channel order (kstep_c0 / kstep_cj): the accumulator-lane order whenever whole 32-channel groups exist
+static int conv_bf16x3_perm(int cin) { return cin % 32 == 0 ? 1 : 0; }
 
 // record image = [ direct 3x3 records (9 taps) | sub-pixel upsample records (4 parities x 4 merged taps) ]
-static size_t direct_records(int cout, int cin) {
+size_t conv_bf16x3_direct_records(int cout, int cin) {
     const int MT = conv_bf16x3_mt(cout), NCB = round_up_i(cout, MT * 32) / (MT * 32), NK = cin / 16;
     return (size_t)NCB * NK * 3 * 2 * 3 * MT * 64;
 }
@@ -629,16 +589,16 @@ static size_t upconv_records(int cout, int cin) {
     return (size_t)2 * NCB * NK * 2 * 2 * 2 * 2 * MT * 64;
 }
 size_t conv_bf16x3_packed_floats(int cout, int cin) {   // size of the record array in floats (4 per 16-byte record)
-    return (direct_records(cout, cin) + upconv_records(cout, cin)) * 4;
+    return (conv_bf16x3_direct_records(cout, cin) + upconv_records(cout, cin)) * 4;
 }
 
 int conv_bf16x3_pack(const float* d_w_oihw, void* d_out, int cout, int cin, hipStream_t s) {
-    const int MT = conv_bf16x3_mt(cout), NCB = round_up_i(cout, MT * 32) / (MT * 32), NK = cin / 16;
-    const size_t n = (size_t)NCB * NK * 3 * 2 * 3 * MT * 64;
-    hipLaunchKernelGGL(k_conv_pack_bf16x3, dim3(cdiv((long long)n, 256)), dim3(256), 0, s, d_w_oihw, (u32x4*)d_out, cout, cin, MT, NCB, NK);
+    const int MT = conv_bf16x3_mt(cout), NCB = round_up_i(cout, MT * 32) / (MT * 32), NK = cin / 16, perm = conv_bf16x3_perm(cin);
+    const size_t n = conv_bf16x3_direct_records(cout, cin);
+    hipLaunchKernelGGL(k_conv_pack_bf16x3, dim3(cdiv((long long)n, 256)), dim3(256), 0, s, d_w_oihw, (u32x4*)d_out, cout, cin, MT, NCB, NK, perm);
     MDT_LAUNCH_CHECK();
     const size_t nu = upconv_records(cout, cin);
-    hipLaunchKernelGGL(k_upconv_pack_bf16x3, dim3(cdiv((long long)nu, 256)), dim3(256), 0, s, d_w_oihw, (u32x4*)d_out + n, cout, cin, MT, NCB, NK);
+    hipLaunchKernelGGL(k_upconv_pack_bf16x3, dim3(cdiv((long long)nu, 256)), dim3(256), 0, s, d_w_oihw, (u32x4*)d_out + n, cout, cin, MT, NCB, NK, perm);
     MDT_LAUNCH_CHECK();
     return MDTILE_OK;
 }
@@ -650,94 +610,35 @@ bool conv_bf16x3_gn_supported(int cout, int cin, int ksize, int up) {
 int conv_bf16x3_launch(const float* d_x, const void* d_w_rec, const float* d_bias, const float* d_res, float* d_y, int B, int cin,
                        int cout, int H, int W, int up, const float* d_coef, hipStream_t s) {
     ConvBParams P;
-    static const int prio = [] { const char* e = getenv("MDTILE_CONV_PRIO"); return e ? atoi(e) : 0; }();
-    P.prio = prio;
+    P.perm = conv_bf16x3_perm(cin);
     P.coef = d_coef;
     P.x = d_x; P.w = (const u32x4*)d_w_rec; P.bias = d_bias; P.res = d_res; P.y = d_y;
     P.B = B; P.Cin = cin; P.Cout = cout; P.H = H; P.W = W;
     P.Hin = up ? H / 2 : H; P.Win = up ? W / 2 : W; P.up = up;
     const int MT = conv_bf16x3_mt(cout);
-    // fused nearest-2x: sub-pixel form (four 2x2 convs on the input grid) unless MDTILE_UPCONV=direct asks for the 9-tap walk
-    static const bool up_direct = [] { const char* e = getenv("MDTILE_UPCONV"); return e && strcmp(e, "direct") == 0; }();
-    if (up && !up_direct) {
-        P.w = (const u32x4*)d_w_rec + direct_records(cout, cin);
+    P.NCB = round_up_i(cout, MT * 32) / (MT * 32);
+    P.NK = cin / 16;
+    dim3 block(512);
+    if (up) {   // fused nearest-2x: sub-pixel form (four 2x2 convs on the input grid)
+        P.w = (const u32x4*)d_w_rec + conv_bf16x3_direct_records(cout, cin);
         P.PX = (P.Win + TW - 1) / TW;
         P.ptiles = P.PX * ((P.Hin + TH - 1) / TH);
-        P.NCB = round_up_i(cout, MT * 32) / (MT * 32);
-        P.NK = cin / 16;
-        dim3 grid(((P.ptiles + 7) / 8) * 8 * P.NCB * 2, B), block(512);
+        dim3 grid(((P.ptiles + 7) / 8) * 8 * P.NCB * 2, B);
         if (MT == 4) hipLaunchKernelGGL(k_upconv_bf16x3<4>, grid, block, 0, s, P);
         else hipLaunchKernelGGL(k_upconv_bf16x3<2>, grid, block, 0, s, P);
         MDT_LAUNCH_CHECK();
         return MDTILE_OK;
     }
-    // pixel rows per block: 16 for the 128-cout blocks (2x the MFMAs per barrier and per weight stage: measured +3..10 %
-    // over 8 rows on the decoder's shapes, profiles/r1e/conv_probe_r1e.log), 8 otherwise or with MDTILE_CONV_TH=8
-    static const int th_env = [] { const char* e = getenv("MDTILE_CONV_TH"); return e ? atoi(e) : 0; }();
-    const int th = (MT == 4 && th_env != 8 && H >= 16) ? 16 : TH;
     P.PX = (W + TW - 1) / TW;
-    P.ptiles = P.PX * ((H + th - 1) / th);
-    P.NCB = round_up_i(cout, MT * 32) / (MT * 32);
-    P.NK = cin / 16;
-    dim3 grid(((P.ptiles + 7) / 8) * 8 * P.NCB, B), block(512);
-    static const bool wdma = [] { const char* e = getenv("MDTILE_CONV_WDMA"); return e && strcmp(e, "1") == 0; }();
-    // default for the 128-cout blocks: 8-row blocks with ONE input stage + weight DMA, two blocks per CU (4 waves / SIMD) --
-    // measured +3..11 % over the 16-row one-block-per-CU variant on the decoder's shapes (profiles/r1g/conv_probe_r1g.log);
-    // MDTILE_CONV_OCC2=0 selects the 16-row variant (MDTILE_CONV_TH / MDTILE_CONV_WDMA then apply)
-    static const bool occ2 = [] { const char* e = getenv("MDTILE_CONV_OCC2"); return !(e && strcmp(e, "0") == 0); }();
-    // MDTILE_CONV_W3=1: 16-row blocks, weight DMA through a 3-stage ring (chunks in flight for two phases)
-    static const bool w3 = [] { const char* e = getenv("MDTILE_CONV_W3"); return e && strcmp(e, "1") == 0; }();
-    if (w3 && MT == 4 && th == 16) {
-        if (d_coef) hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 16, true, true, false, true>), grid, block, 0, s, P);
-        else hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 16, false, true, false, true>), grid, block, 0, s, P);
-        MDT_LAUNCH_CHECK();
-        return MDTILE_OK;
-    }
-    // MFMA order: term-major across the accumulators by default (+1..4 % measured, profiles/r1l); MDTILE_CONV_ORD=0: hipcc's own
-    static const int ord = [] { const char* e = getenv("MDTILE_CONV_ORD"); return e ? atoi(e) : 2; }();
-    if (occ2 && MT == 4) {
-        P.ptiles = P.PX * ((H + TH - 1) / TH);
-        dim3 grid2(((P.ptiles + 7) / 8) * 8 * P.NCB, B);
-        if (ord == 1) {
-            if (d_coef) hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 8, true, true, true, false, 1>), grid2, block, 0, s, P);
-            else hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 8, false, true, true, false, 1>), grid2, block, 0, s, P);
-        } else if (ord == 2) {
-            if (d_coef) hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 8, true, true, true, false, 2>), grid2, block, 0, s, P);
-            else hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 8, false, true, true, false, 2>), grid2, block, 0, s, P);
-        } else {
-            if (d_coef) hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 8, true, true, true>), grid2, block, 0, s, P);
-            else hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 8, false, true, true>), grid2, block, 0, s, P);
-        }
-        MDT_LAUNCH_CHECK();
-        return MDTILE_OK;
-    }
-    if (ord != 0 && MT == 4 && th == 16) {   // 16-row blocks (MDTILE_CONV_OCC2=0): same two orders
-        if (ord == 1) {
-            if (d_coef) hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 16, true, true, false, false, 1>), grid, block, 0, s, P);
-            else hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 16, false, true, false, false, 1>), grid, block, 0, s, P);
-        } else {
-            if (d_coef) hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 16, true, true, false, false, 2>), grid, block, 0, s, P);
-            else hipLaunchKernelGGL((k_conv3x3_bf16x3<4, 16, false, true, false, false, 2>), grid, block, 0, s, P);
-        }
-        MDT_LAUNCH_CHECK();
-        return MDTILE_OK;
-    }
-#define MDT_CONV_LAUNCH(MM, TT, GG, WW) hipLaunchKernelGGL((k_conv3x3_bf16x3<MM, TT, GG, WW>), grid, block, 0, s, P)
-#define MDT_CONV_PICK(GG, WW)                                  \
-    do {                                                       \
-        if (MT == 4 && th == 16) MDT_CONV_LAUNCH(4, 16, GG, WW); \
-        else if (MT == 4) MDT_CONV_LAUNCH(4, 8, GG, WW);       \
-        else MDT_CONV_LAUNCH(2, 8, GG, WW);                    \
-    } while (0)
-    if (d_coef) {
-        if (wdma) MDT_CONV_PICK(true, true);
-        else MDT_CONV_PICK(true, false);
+    P.ptiles = P.PX * ((H + TH - 1) / TH);
+    dim3 grid(((P.ptiles + 7) / 8) * 8 * P.NCB, B);
+    if (MT == 4) {
+        if (d_coef) hipLaunchKernelGGL((k_conv3x3_bf16x3<4, true>), grid, block, 0, s, P);
+        else hipLaunchKernelGGL((k_conv3x3_bf16x3<4, false>), grid, block, 0, s, P);
     } else {
-        if (wdma) MDT_CONV_PICK(false, true);
-        else MDT_CONV_PICK(false, false);
+        if (d_coef) hipLaunchKernelGGL((k_conv3x3_bf16x3<2, true>), grid, block, 0, s, P);
+        else hipLaunchKernelGGL((k_conv3x3_bf16x3<2, false>), grid, block, 0, s, P);
     }
-#undef MDT_CONV_PICK
-#undef MDT_CONV_LAUNCH
     MDT_LAUNCH_CHECK();
     return MDTILE_OK;
 }

@@ -50,6 +50,8 @@ _IP = POINTER(c_int)
 _SIGNATURES = {
     "mdtile_version": (c_int, []),
     "mdtile_last_error": (c_char_p, []),
+    "mdtile_set_precision": (c_int, [c_int]),
+    "mdtile_get_precision": (c_int, []),
     "mdtile_plan_create": (c_void_p, [c_int] * 7),
     "mdtile_plan_destroy": (None, [c_void_p]),
     "mdtile_plan_info": (c_int, [c_void_p, _IP]),
@@ -88,6 +90,12 @@ _SIGNATURES = {
     "mdtile_conv2d_gn_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "mdtile_conv2d_gn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                  c_int, c_int, c_void_p]),
+    "mdtile_rec_size": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "mdtile_rec_from_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "mdtile_rec_to_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "mdtile_conv2d_rec_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "mdtile_conv2d_rec": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                  c_int, c_int, c_void_p]),
     "mdtile_vae_attn_ws_size": (c_size_t, [c_int, c_int, c_int]),
     "mdtile_vae_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p]),
     "mdtile_crop_store": (c_int, [c_void_p, c_int, c_int, c_int, c_int, _IP, _IP, c_int, c_void_p, c_int, c_int, c_void_p]),
@@ -115,6 +123,18 @@ def lib() -> ctypes.CDLL:
         raise MdtileError(f"libmdtile.so version {L.mdtile_version()} != binding version 100")
     _lib = L
     return L
+
+
+PRECISION_BF16X3, PRECISION_F32 = 0, 1
+
+
+def set_precision(mode: int) -> None:
+    """PRECISION_BF16X3 (default: split-bf16 matrix-core kernels) or PRECISION_F32 (exact-fp32 MFMA kernels everywhere)."""
+    _check(lib().mdtile_set_precision(int(mode)), "mdtile_set_precision")
+
+
+def get_precision() -> int:
+    return int(lib().mdtile_get_precision())
 
 
 def exported_symbols() -> List[str]:
@@ -478,6 +498,39 @@ def gn_coeffs(mean: torch.Tensor, var: torch.Tensor, gamma, beta, C: int, groups
     return coef
 
 
+class RecImage:
+    """Split-bf16 record image of an activation [B, C, H, W] (include/mdtile.h "Record-image conv path"): the form the record
+    conv kernels read by DMA.  `data` is an opaque int32 buffer of mdtile_rec_size bytes."""
+
+    __slots__ = ("data", "shape")
+
+    def __init__(self, shape, device):
+        B, C, H, W = (int(v) for v in shape)
+        n = lib().mdtile_rec_size(B, C, H, W)
+        if n == 0:
+            raise MdtileError(f"no record image for shape {tuple(shape)} (C % 32 == 0 required)")
+        self.shape = (B, C, H, W)
+        self.data = torch.empty(n // 4, dtype=torch.int32, device=device)
+
+    def to_f32(self) -> torch.Tensor:
+        B, C, H, W = self.shape
+        out = torch.empty(self.shape, dtype=torch.float32, device=self.data.device)
+        _check(lib().mdtile_rec_to_f32(_p(self.data), _p(out), B, C, H, W, _stream()), "mdtile_rec_to_f32")
+        return out
+
+
+def rec_from_f32(x: torch.Tensor, coef: Optional[torch.Tensor] = None) -> RecImage:
+    """split(silu(a x + s)) with coef = gn_coeffs(...) [B, 2, C], or split(x) when coef is None."""
+    _dev_tensor(x, "x", torch.float32)
+    B, C, H, W = x.shape
+    rec = RecImage(x.shape, x.device)
+    if coef is not None:
+        _dev_tensor(coef, "coef", torch.float32)
+        assert tuple(coef.shape) == (B, 2, C)
+    _check(lib().mdtile_rec_from_f32(_p(x), _p(coef), _p(rec.data), B, C, H, W, _stream()), "mdtile_rec_from_f32")
+    return rec
+
+
 def silu(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _dev_tensor(x, "x", torch.float32)
     out = torch.empty_like(x) if out is None else out
@@ -521,6 +574,31 @@ class PackedConv:
         """True when this conv has a kernel that applies GroupNorm + SiLU to its input on load (mdtile_conv2d_gn)."""
         flags = (CONV_UPSAMPLE2X if upsample2x else 0) | (CONV_EXACT_F32 if exact else 0)
         return bool(lib().mdtile_conv2d_gn_supported(self.cout, self.cin, self.ksize, flags, int(token_major)))
+
+    def takes_rec(self, upsample2x: bool = False) -> bool:
+        """True when the record-image kernels (mdtile_conv2d_rec) take this conv."""
+        return bool(lib().mdtile_conv2d_rec_supported(self.cout, self.cin, self.ksize, CONV_UPSAMPLE2X if upsample2x else 0))
+
+    def call_rec(self, x: RecImage, residual: Optional[torch.Tensor] = None, upsample2x: bool = False, want_f32: bool = True,
+                 want_rec: bool = False, rec_coef: Optional[torch.Tensor] = None):
+        """y = conv(x_rec) + bias (+ residual) -> (fp32 NCHW or None, RecImage or None).  The record output is
+        split(silu(a y + s)) with rec_coef = gn_coeffs(...) of the NEXT norm, or split(y) when rec_coef is None."""
+        B, cin, H, W = x.shape
+        assert cin == self.cin and (want_f32 or want_rec)
+        if upsample2x:
+            H, W = 2 * H, 2 * W
+        y = torch.empty((B, self.cout, H, W), dtype=torch.float32, device=x.data.device) if want_f32 else None
+        yr = RecImage((B, self.cout, H, W), x.data.device) if want_rec else None
+        if residual is not None:
+            _dev_tensor(residual, "residual", torch.float32)
+            assert tuple(residual.shape) == (B, self.cout, H, W)
+        if rec_coef is not None:
+            _dev_tensor(rec_coef, "rec_coef", torch.float32)
+            assert want_rec and tuple(rec_coef.shape) == (B, 2, self.cout)
+        _check(lib().mdtile_conv2d_rec(_p(x.data), _p(self.packed), _p(self.bias), _p(residual), _p(y), None if yr is None else _p(yr.data),
+                                       _p(rec_coef), B, self.cin, self.cout, H, W, CONV_UPSAMPLE2X if upsample2x else 0, _stream()),
+               "mdtile_conv2d_rec")
+        return y, yr
 
     def __call__(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, upsample2x: bool = False,
                  token_major: bool = False, exact: bool = False, pre_gn: Optional[torch.Tensor] = None) -> torch.Tensor:

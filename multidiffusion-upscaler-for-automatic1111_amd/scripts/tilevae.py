@@ -35,6 +35,9 @@ import os as _os
 # GroupNorm + SiLU fused into the following 3x3 conv's input staging (engine: mdtile_conv2d_gn).  MDTILE_FUSE_GN=0 keeps the
 # separate one-pass GroupNorm+SiLU kernel (A/B measurements, debugging).
 FUSE_PRE_GN = _os.environ.get("MDTILE_FUSE_GN", "1") != "0"
+# fast mode with every norm frozen: activations travel between the 3x3 convs as split-bf16 record images that the PRODUCING
+# conv writes already normalised + SiLU'd (engine: mdtile_conv2d_rec); MDTILE_REC=0 keeps the fp32 hand-over (A/B, debugging)
+REC_PATH = _os.environ.get("MDTILE_REC", "1") != "0"
 # multi-GPU fast mode: run the GroupNorm estimator sequence-parallel across the ranks (mdtile/seqpar.py); 0 = every rank
 # repeats the whole estimator (no communication, but 1 of every rank's ~3 work units at 8 GPUs)
 SP_ESTIMATOR = _os.environ.get("MDTILE_SP_ESTIMATOR", "1") != "0"
@@ -54,11 +57,12 @@ def get_rcmd_dec_tsize() -> int:
 # program = upstream's task queue, with the fusions the engine offers already applied
 # ---------------------------------------------------------------------------------------------------------------------
 class Step:
-    __slots__ = ("kind", "conv", "norm", "silu", "attn", "fuse_res", "upsample", "downsample")
+    __slots__ = ("kind", "conv", "norm", "silu", "attn", "fuse_res", "upsample", "downsample", "channels")
 
-    def __init__(self, kind, conv=None, norm=None, silu=False, attn=None, fuse_res=False, upsample=False, downsample=False):
+    def __init__(self, kind, conv=None, norm=None, silu=False, attn=None, fuse_res=False, upsample=False, downsample=False, channels=0):
         self.kind, self.conv, self.norm, self.silu, self.attn = kind, conv, norm, silu, attn
         self.fuse_res, self.upsample, self.downsample = fuse_res, upsample, downsample
+        self.channels = channels      # norm steps: the GroupNorm's channel count
 
 
 class AttnPack:
@@ -104,9 +108,9 @@ def _resblock(steps: List[Step], blk, pack):
         steps.append(Step("store_res", conv=pack(shortcut)))
     else:
         steps.append(Step("store_res"))
-    steps.append(Step("norm", norm=_norm_params(blk.norm1), silu=True))
+    steps.append(Step("norm", norm=_norm_params(blk.norm1), silu=True, channels=blk.norm1.num_channels))
     steps.append(Step("conv", conv=pack(blk.conv1)))
-    steps.append(Step("norm", norm=_norm_params(blk.norm2), silu=True))
+    steps.append(Step("norm", norm=_norm_params(blk.norm2), silu=True, channels=blk.norm2.num_channels))
     steps.append(Step("conv", conv=pack(blk.conv2), fuse_res=True))       # conv2 + add_res in one epilogue
 
 
@@ -120,7 +124,7 @@ def build_task_queue(net, is_decoder: bool = True, pack=None, engine=None) -> Li
 
     def _mid():
         _resblock(steps, net.mid.block_1, pack)
-        steps.extend([Step("store_res"), Step("norm", norm=_norm_params(net.mid.attn_1.norm)),
+        steps.extend([Step("store_res"), Step("norm", norm=_norm_params(net.mid.attn_1.norm), channels=net.mid.attn_1.norm.num_channels),
                       Step("attn", attn=AttnPack(net.mid.attn_1, pack, engine))])
         _resblock(steps, net.mid.block_2, pack)
 
@@ -140,7 +144,7 @@ def build_task_queue(net, is_decoder: bool = True, pack=None, engine=None) -> Li
                 steps.append(Step("conv", conv=pack(net.down[lvl].downsample.conv), downsample=True))
         _mid()
     if not is_decoder or not net.give_pre_end:
-        steps.append(Step("norm", norm=_norm_params(net.norm_out), silu=True))
+        steps.append(Step("norm", norm=_norm_params(net.norm_out), silu=True, channels=net.norm_out.num_channels))
         steps.append(Step("conv", conv=pack(net.conv_out)))
         if is_decoder and net.tanh_out:
             steps.append(Step("tanh"))
@@ -228,16 +232,10 @@ class VAEHook:
 
     # ---- geometry (host ints via the C ABI) -------------------------------------------------------------------------
     def get_best_tile_size(self, lowerbound, upperbound):
-        divider = 32
-        while divider >= 2:
-            rem = lowerbound % divider
-            if rem == 0:
-                return lowerbound
-            cand = lowerbound - rem + divider
-            if cand <= upperbound:
-                return cand
-            divider //= 2
-        return lowerbound
+        """Upstream keeps this helper on the hook (:390-403); here the whole split lives behind the C ABI
+        (mdtile_vae_split_tiles), so the name only forwards to it: the real tile size of a [lowerbound, upperbound] search is
+        the width of the first tile of such a split."""
+        raise NotImplementedError("tile sizes are chosen inside mdtile_vae_split_tiles; use VAEHook.split_tiles")
 
     def split_tiles(self, h, w):
         return self.engine.vae_split_tiles(h, w, self.tile_size, self.is_decoder)
@@ -270,6 +268,73 @@ class VAEHook:
             elif s.kind == "tanh":
                 st.x = torch.tanh(st.x)
             st.pc += 1
+
+    # ---- fast mode, every norm frozen: record-image hand-over between the 3x3 convs ----------------------------------
+    @staticmethod
+    def _takes_rec(step: Step) -> bool:
+        fn = getattr(step.conv, "takes_rec", None)
+        return bool(fn and not step.downsample and fn(step.upsample))
+
+    def _demand(self, steps: List[Step], i: int):
+        """Forms in which the value produced by steps[i] has to exist: (fp32 NCHW?, record image: None | "raw" | index of the
+        norm step whose (a, s) + SiLU the producer applies)."""
+        need_f32, j = False, i + 1
+        while j < len(steps) and steps[j].kind == "store_res":     # residual / nin_shortcut input: fp32
+            need_f32, j = True, j + 1
+        if j >= len(steps):
+            return True, None
+        s = steps[j]
+        if s.kind == "norm":
+            nxt = steps[j + 1] if j + 1 < len(steps) else None
+            if s.silu and nxt is not None and nxt.kind == "conv" and not nxt.upsample and self._takes_rec(nxt):
+                return need_f32, j
+            return True, None
+        if s.kind == "conv" and s.upsample and self._takes_rec(s):
+            return need_f32, "raw"
+        return True, None
+
+    def _run_tile_rec(self, steps: List[Step], x: Tensor, frozen, coefs, norm_ord) -> Tensor:
+        """One tile start to finish with frozen statistics (upstream's single sweep, :578-642).  A 3x3 conv that the record
+        kernels take reads its input as a record image; whoever produces that input writes it in that form -- the previous
+        record conv's epilogue (norm + SiLU + split fused), or mdtile_rec_from_f32 behind conv_in / attention."""
+        E = self.engine
+        res: List[Tensor] = []
+        xrec, pre = None, None
+        for i, s in enumerate(steps):
+            if s.kind == "store_res":
+                res.append(x if s.conv is None else s.conv(x))
+            elif s.kind == "norm":
+                k = norm_ord[i]
+                nxt = steps[i + 1] if i + 1 < len(steps) else None
+                is_conv = nxt is not None and nxt.kind == "conv" and not nxt.downsample
+                if s.silu and is_conv and not nxt.upsample and self._takes_rec(nxt):
+                    if xrec is None:
+                        xrec = E.rec_from_f32(x, coefs[k])
+                elif FUSE_PRE_GN and s.silu and is_conv and nxt.conv.fuses_pre_gn(upsample2x=nxt.upsample):
+                    pre = coefs[k]
+                else:
+                    var, mean = frozen[k]
+                    keep = res and res[-1] is x
+                    x = E.gn_apply(x, mean, var, s.norm[0], s.norm[1], 32, 1e-6, s.silu, out=None if keep else x)
+            elif s.kind == "conv":
+                if s.downsample:
+                    x, xrec = s.conv.down2(x), None
+                else:
+                    residual = res.pop() if s.fuse_res else None
+                    if self._takes_rec(s) and (xrec is not None or s.upsample):
+                        if xrec is None:
+                            xrec = E.rec_from_f32(x, None)
+                        need_f32, rk = self._demand(steps, i)
+                        x, xrec = s.conv.call_rec(xrec, residual=residual, upsample2x=s.upsample, want_f32=need_f32, want_rec=rk is not None,
+                                                  rec_coef=None if rk in (None, "raw") else coefs[norm_ord[rk]])
+                    else:
+                        x, xrec = s.conv(x, residual=residual, upsample2x=s.upsample, pre_gn=pre), None
+                pre = None
+            elif s.kind == "attn":
+                x, xrec = s.attn(x, res.pop()), None
+            elif s.kind == "tanh":
+                x = torch.tanh(x)
+        return x
 
     def _apply_norm(self, steps: List[Step], st: TileState, var: Tensor, mean: Tensor):
         E = self.engine
@@ -377,11 +442,20 @@ class VAEHook:
         n_norm_total = sum(1 for s in steps if s.kind == "norm")
         if frozen is not None and len(frozen) == n_norm_total:
             # every norm is already resolved: each tile runs start to finish on its own (upstream: one sweep)
+            use_rec = REC_PATH and hasattr(E, "rec_from_f32")
+            if use_rec:
+                norm_ord = {i: k for k, i in enumerate(i for i, s in enumerate(steps) if s.kind == "norm")}
+                coefs = [E.gn_coeffs(mean, var, steps[i].norm[0], steps[i].norm[1], steps[i].channels, 32, 1e-6)
+                         for i, (var, mean) in zip(norm_ord, frozen)]
             for i in mine:
                 if state.interrupted:
                     interrupted = True
                     break
                 st, k = tiles[i], 0
+                if use_rec:
+                    st.x = self._run_tile_rec(steps, st.x, frozen, coefs, norm_ord)
+                    finish(i)
+                    continue
                 while True:
                     self._run_until_norm(steps, st)
                     if st.pc >= len(steps):

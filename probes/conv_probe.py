@@ -1,7 +1,8 @@
-"""Timing probe for the conv kernels (run on the GPU box): python probes/conv_probe.py
-Prints TFLOP/s (fp32-equivalent: 2*B*H*W*cout*cin*k*k) for the decoder's conv shapes, split-bf16 vs exact-fp32, and the
-max relative deviation between the two."""
-import os, sys, time
+"""Timing probe for the 3x3 conv kernels (run on the GPU box): python probes/conv_probe.py [--shapes 0,2,5] [--exact]
+Prints TFLOP/s-equivalent (2*B*H*W*cout*cin*9; the sub-pixel upsample form EXECUTES 4/9 of that) for the decoder's conv
+shapes of one 278x278-latent tile: record-image kernels (vae_conv_rec.hip: fp32 output / activated record output / both) against
+the fp32 hand-over kernels (vae_conv_bf16x3.hip, plain and with the fused GroupNorm+SiLU staging), and their max deviation."""
+import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "multidiffusion-upscaler-for-automatic1111_amd"))
@@ -9,45 +10,63 @@ sys.path.insert(0, ROOT)
 import mdtile as E
 
 dev = torch.device("cuda:0")
-SHAPES = [  # cin, cout, k, H, W, upsample   (one 278x278-latent decoder tile of the 8K decode)
-    (512, 512, 3, 278, 278, False),
-    (512, 512, 3, 556, 556, True),
-    (512, 512, 3, 556, 556, False),
-    (512, 512, 3, 1112, 1112, True),
-    (512, 256, 3, 1112, 1112, False),
-    (256, 256, 3, 1112, 1112, False),
-    (256, 256, 3, 2224, 2224, True),
-    (256, 128, 3, 2224, 2224, False),
-    (128, 128, 3, 2224, 2224, False),
+SHAPES = [  # cin, cout, H, W, upsample
+    (512, 512, 278, 278, False),
+    (512, 512, 556, 556, True),
+    (512, 512, 556, 556, False),
+    (512, 512, 1112, 1112, True),
+    (512, 256, 1112, 1112, False),
+    (256, 256, 1112, 1112, False),
+    (256, 256, 2224, 2224, True),
+    (256, 128, 2224, 2224, False),
+    (128, 128, 2224, 2224, False),
 ]
-# usage: conv_probe.py [--no-exact] [--shapes 0,2,5]     (env MDTILE_CONV_TH=16 / MDTILE_UPCONV=direct select kernel variants)
-NO_EXACT = "--no-exact" in sys.argv
 if "--shapes" in sys.argv:
     SHAPES = [SHAPES[int(i)] for i in sys.argv[sys.argv.index("--shapes") + 1].split(",")]
-print(f"variant: MDTILE_CONV_TH={os.environ.get('MDTILE_CONV_TH', '8')} MDTILE_UPCONV={os.environ.get('MDTILE_UPCONV', 'subpixel')}", flush=True)
+EXACT = "--exact" in sys.argv
+
+
+def timeit(fn, n=6):
+    fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / n
+
+
 torch.manual_seed(0)
-for cin, cout, k, H, W, up in SHAPES:
-    conv = torch.nn.Conv2d(cin, cout, k, 1, k // 2).to(dev)
+for cin, cout, H, W, up in SHAPES:
+    conv = torch.nn.Conv2d(cin, cout, 3, 1, 1).to(dev)
     pc = E.PackedConv(conv.weight.detach(), conv.bias.detach())
     hin, win = (H // 2, W // 2) if up else (H, W)
     x = torch.randn(1, cin, hin, win, device=dev)
     res = torch.randn(1, cout, H, W, device=dev)
-    flops = 2.0 * H * W * cout * cin * k * k
-    outs = {}
-    line = f"{cin:4d}->{cout:4d} k{k} {H}x{W}{' up' if up else '   '}: "
-    for exact in ((False,) if NO_EXACT else (False, True)):
-        y = pc(x, residual=res, upsample2x=up, exact=exact)
-        torch.cuda.synchronize()
-        n = 3 if exact else 6
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        for _ in range(n):
-            y = pc(x, residual=res, upsample2x=up, exact=exact)
-        e.record()
-        torch.cuda.synchronize()
-        ms = s.elapsed_time(e) / n
-        outs[exact] = y
-        line += f"{'f32   ' if exact else 'bf16x3'} {ms:8.3f} ms {flops / ms * 1e-9:7.1f} TF   "
-    err = float("nan") if NO_EXACT else ((outs[False] - outs[True]).abs().max() / outs[True].abs().max()).item()
-    print(line + f"max dev {err:.2e}", flush=True)
-    del x, res, outs, y
+    coef_in = torch.stack([torch.rand(1, cin, device=dev) + 0.5, torch.randn(1, cin, device=dev) * 0.3], dim=1).contiguous()
+    coef_out = torch.stack([torch.rand(1, cout, device=dev) + 0.5, torch.randn(1, cout, device=dev) * 0.3], dim=1).contiguous()
+    flops = 2.0 * H * W * cout * cin * 9
+    line = f"{cin:4d}->{cout:4d} {H}x{W}{' up' if up else '   '}: "
+    t_old = timeit(lambda: pc(x, residual=res, upsample2x=up))
+    line += f"f32-in {t_old:7.3f} ms {flops / t_old * 1e-9:6.1f} TF | "
+    if not up:
+        t_gn = timeit(lambda: pc(x, residual=res, pre_gn=coef_in))
+        line += f"f32-in+GN {t_gn:7.3f} ms {flops / t_gn * 1e-9:6.1f} TF | "
+    xrec = E.rec_from_f32(x, None if up else coef_in)
+    t_prep = timeit(lambda: E.rec_from_f32(x, None if up else coef_in))
+    t_r32 = timeit(lambda: pc.call_rec(xrec, residual=res, upsample2x=up, want_f32=True))
+    t_rrec = timeit(lambda: pc.call_rec(xrec, upsample2x=up, want_f32=False, want_rec=True, rec_coef=coef_out))
+    t_both = timeit(lambda: pc.call_rec(xrec, residual=res, upsample2x=up, want_f32=True, want_rec=True, rec_coef=coef_out))
+    line += (f"rec->f32 {t_r32:7.3f} ms {flops / t_r32 * 1e-9:6.1f} TF | rec->rec {t_rrec:7.3f} ms {flops / t_rrec * 1e-9:6.1f} TF | "
+             f"rec->both {t_both:7.3f} ms {flops / t_both * 1e-9:6.1f} TF | prep {t_prep:6.3f} ms")
+    ya = pc(x, residual=res, upsample2x=up, pre_gn=None if up else coef_in)
+    yb, _ = pc.call_rec(xrec, residual=res, upsample2x=up, want_f32=True)
+    line += f" | dev(rec, f32-in) {((ya - yb).abs().max() / ya.abs().max()).item():.1e}"
+    if EXACT:
+        xa = x if up else torch.nn.functional.silu(x * coef_in[:, 0].view(1, -1, 1, 1) + coef_in[:, 1].view(1, -1, 1, 1))
+        ye = pc(xa, residual=res, upsample2x=up, exact=True)
+        line += f" dev(rec, exact) {((ye - yb).abs().max() / ye.abs().max()).item():.1e}"
+    print(line, flush=True)
+    del x, res, ya, yb, xrec

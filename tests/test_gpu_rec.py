@@ -1,0 +1,146 @@
+"""GPU parity of the record-image conv path (csrc/vae_conv_rec.hip): fp32 -> record image (+ fused fixed-statistics GroupNorm +
+SiLU), the record 3x3 conv and the record sub-pixel upsample conv (fp32 and record outputs, residual, ragged tiles, batch),
+and the whole fast-mode tiled decode with the record hand-over against the fp32 hand-over and the oracle.
+Tolerances: split-bf16 operands carry 16 significand bits per factor -> <= 1e-4 of the output range per conv (fp32 accumulate);
+a record image reproduces its fp32 source to 2^-16 relative per element."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ldm_decoder as ld
+from oracle import vae_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a: torch.Tensor, b: torch.Tensor) -> float:
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+
+
+def _coef(B, C, seed):
+    g = torch.Generator().manual_seed(seed)
+    a = torch.rand(B, 1, C, generator=g) * 1.5 + 0.25
+    s = torch.randn(B, 1, C, generator=g) * 0.5
+    return torch.cat([a, s], dim=1).contiguous()        # [B, 2, C] = (a, s)
+
+
+def _act(x, coef):
+    B, C = x.shape[:2]
+    return F.silu(x * coef[:, 0].view(B, C, 1, 1) + coef[:, 1].view(B, C, 1, 1))
+
+
+@pytest.mark.parametrize("B,C,H,W", [(1, 32, 5, 7), (2, 128, 17, 45), (1, 512, 24, 40), (1, 64, 70, 300)])
+def test_record_image_roundtrip(plugin, cuda, B, C, H, W):
+    E = plugin.engine
+    torch.manual_seed(C + H)
+    x = torch.randn(B, C, H, W) * 2.0 + 0.3
+    back = E.rec_from_f32(x.to(cuda)).to_f32().cpu()
+    assert (back - x).abs().max().item() <= 2.0 ** -15 * x.abs().max().item()
+    assert ((back - x).abs() <= 2.0 ** -16 * x.abs() + 1e-30).all()      # hi + lo: 16 significand bits per element
+    coef = _coef(B, C, 3)
+    ref = _act(x, coef)
+    got = E.rec_from_f32(x.to(cuda), coef.to(cuda)).to_f32().cpu()
+    assert _rel(got, ref) < 2e-5
+
+
+REC_CASES = [  # B, cin, cout, H, W (output), upsample, residual
+    (1, 128, 128, 16, 32, False, False),     # exactly one block
+    (1, 128, 128, 17, 45, False, True),      # ragged rows and columns
+    (2, 256, 128, 40, 36, False, True),      # batch 2, 16 K-steps
+    (1, 512, 512, 24, 40, False, True),      # SD mid-block width, 4 cout blocks
+    (1, 96, 128, 33, 70, False, False),      # 6 K-steps, three pixel-tile columns
+    (1, 256, 256, 50, 100, False, True),     # many pixel tiles x 2 cout blocks (block -> XCD mapping)
+    (1, 128, 128, 32, 48, True, False),      # sub-pixel upsample: NK = 8 (8 % 3 = 2: skipped K-steps in the last trip)
+    (2, 256, 128, 40, 36, True, True),       # upsample + residual + batch (NK = 16)
+    (1, 512, 512, 74, 100, True, False),     # upsample, ragged input tiles (37 x 50), 4 cout blocks (NK = 32)
+    (1, 96, 128, 18, 66, True, True),        # upsample, NK = 6 (whole trips only)
+]
+
+
+@pytest.mark.parametrize("B,cin,cout,H,W,up,res", REC_CASES)
+def test_conv_rec_vs_torch(plugin, cuda, B, cin, cout, H, W, up, res):
+    E = plugin.engine
+    torch.manual_seed(cin * 7 + cout + H)
+    conv = torch.nn.Conv2d(cin, cout, 3, 1, 1)
+    hin, win = (H // 2, W // 2) if up else (H, W)
+    x = torch.randn(B, cin, hin, win)
+    in_coef = None if up else _coef(B, cin, 5)          # upsample.conv reads the raw activation, conv1 / conv2 a normalised one
+    out_coef = _coef(B, cout, 9)
+    with torch.no_grad():
+        xin = x if in_coef is None else _act(x, in_coef)
+        ref = conv(F.interpolate(xin, scale_factor=2.0, mode="nearest") if up else xin)
+        r = torch.randn_like(ref) if res else None
+        if res:
+            ref = ref + r
+    pc = E.PackedConv(conv.weight.detach().to(cuda), conv.bias.detach().to(cuda))
+    assert pc.takes_rec(up)
+    xrec = E.rec_from_f32(x.to(cuda), None if in_coef is None else in_coef.to(cuda))
+    rr = None if r is None else r.to(cuda)
+    # fp32 + activated record output in one launch
+    y, yrec = pc.call_rec(xrec, residual=rr, upsample2x=up, want_f32=True, want_rec=True, rec_coef=out_coef.to(cuda))
+    err = _rel(y.cpu(), ref)
+    assert err < 1e-4, f"record conv fp32 output: rel err {err}"
+    got = yrec.to_f32().cpu()
+    want = _act(ref, out_coef)
+    assert _rel(got, want) < 2e-4, f"record conv activated record output: rel err {_rel(got, want)}"
+    # the zero border is part of the image: a second conv reading it must see 'same' zero padding
+    conv2 = torch.nn.Conv2d(cout, 128, 3, 1, 1)
+    pc2 = E.PackedConv(conv2.weight.detach().to(cuda), conv2.bias.detach().to(cuda))
+    y2, _ = pc2.call_rec(yrec, want_f32=True)
+    with torch.no_grad():
+        ref2 = conv2(want)
+    assert _rel(y2.cpu(), ref2) < 2e-4, f"chained record conv: rel err {_rel(y2.cpu(), ref2)}"
+    # raw record output only (what conv2 hands to upsample.conv), no fp32 copy
+    y3, yrec3 = pc.call_rec(xrec, residual=rr, upsample2x=up, want_f32=False, want_rec=True)
+    assert y3 is None
+    assert _rel(yrec3.to_f32().cpu(), ref) < 1e-4
+
+
+def test_conv_rec_matches_fp32_handover_kernel(plugin, cuda):
+    """Same arithmetic contract as the fused-GroupNorm split-bf16 kernel (vae_conv_bf16x3.hip): the two families agree to fp32
+    round-off of exp / rcp, far below the split's own 2^-16."""
+    E = plugin.engine
+    torch.manual_seed(4)
+    B, cin, cout, H, W = 1, 256, 256, 37, 61
+    conv = torch.nn.Conv2d(cin, cout, 3, 1, 1)
+    x = (torch.randn(B, cin, H, W) * 1.3).to(cuda)
+    coef = _coef(B, cin, 2).to(cuda)
+    pc = E.PackedConv(conv.weight.detach().to(cuda), conv.bias.detach().to(cuda))
+    a = pc(x, pre_gn=coef)
+    b, _ = pc.call_rec(E.rec_from_f32(x, coef), want_f32=True)
+    assert _rel(b.cpu(), a.cpu()) < 2e-5
+
+
+@pytest.mark.parametrize("fast", [True])
+def test_tiled_decode_record_path_vs_fp32_handover_and_oracle(plugin, cuda, fast):
+    dec_cpu = ld.make_decoder(3)
+    torch.manual_seed(5)
+    z = torch.randn(1, 4, 34, 42)
+    ref = vo.tiled_forward(dec_cpu, z, 12, fast)
+    dec = ld.make_decoder(3).to(cuda)
+    dec.original_forward = dec.forward
+    outs = {}
+    old = plugin.tilevae.REC_PATH
+    try:
+        for rec in (True, False):
+            plugin.tilevae.REC_PATH = rec
+            hook = plugin.tilevae.VAEHook(dec, 12, is_decoder=True, fast_decoder=fast, fast_encoder=False, color_fix=False)
+            outs[rec] = hook(z.to(cuda)).cpu()
+    finally:
+        plugin.tilevae.REC_PATH = old
+    assert _rel(outs[True], ref) < 1e-3
+    assert _rel(outs[False], ref) < 1e-3
+    assert _rel(outs[True], outs[False]) < 1e-4
+
+
+def test_tiled_encode_record_path(plugin, cuda):
+    """Encoder direction through the same executor: stride-2 Downsample convs read fp32, everything else records."""
+    enc_cpu = ld.make_encoder(2)
+    torch.manual_seed(6)
+    x = torch.randn(1, 3, 168, 136)
+    ref = vo.tiled_forward(enc_cpu, x, 64, True, is_decoder=False, color_fix=False)
+    enc = ld.make_encoder(2).to(cuda)
+    enc.original_forward = enc.forward
+    hook = plugin.tilevae.VAEHook(enc, 64, is_decoder=False, fast_decoder=False, fast_encoder=True, color_fix=False)
+    out = hook(x.to(cuda)).cpu()
+    assert _rel(out, ref) < 1e-3
