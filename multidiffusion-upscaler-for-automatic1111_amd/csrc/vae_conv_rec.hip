@@ -82,98 +82,141 @@ __device__ __forceinline__ void dma16(const char* base, unsigned voff, const u32
 
 __device__ __forceinline__ float silu_f(float t) { return t * __builtin_amdgcn_rcpf(1.0f + __expf(-t)); }
 
-// ---- shared epilogue: acc tile (32 couts x 32 px of one row) -> + bias (+ residual) -> fp32 NCHW and / or record image ----
-// C/D layout of a 32x32 MFMA: col = lane & 31 (pixel), row = (q&3) + 8*(q>>2) + 4*(lane>>5) (cout).
+// ---- shared epilogue: one 32-cout tile of a wave (NROW pixel rows x NPX pixels per lane) -> + bias (+ residual) -> fp32 NCHW
+// and / or record image.  C/D layout of a 32x32 MFMA: col = lane & 31 (pixel), row = (q&3) + 8*(q>>2) + 4*(lane>>5) (cout).
+// The epilogue is latency-, not bandwidth-bound (one block per CU, nothing else to run meanwhile), so it is built to expose
+// as few memory round trips as possible:
+//   * the per-channel constants (bias, and the (a, s) of the record output's activation) of the item's 128 couts are DMA'd
+//     into a 3 x 1 KB LDS buffer together with the item's first operands -- the epilogue reads them with ds_read_b128;
+//   * the residual is requested 32 values per lane at a time (two pixel rows) before the first of them is used.
 struct EpiCtx {
-    const ConvRParams* P;
+    const float* __restrict__ res;
+    float* __restrict__ y32;
+    u32x4* __restrict__ yrec;
+    bool has_bias, has_act;
+    int Cout, H, W;      // output size
     int b, kg;
     size_t HW, planeO;   // fp32 plane, record plane ((H+2)*(W+2))
     int WpO;
 };
 
-template <int NPX>   // NPX = 1: one pixel per lane; NPX = 2: the lane owns output px (2X, 2X+1) (sub-pixel upsample kernel)
-__device__ __forceinline__ void epilogue_tile(const EpiCtx& E, const f32x16 (&acc)[NPX], int mt_global, int y, int x) {
-    const ConvRParams& P = *E.P;
-    const int cbase = mt_global * 32 + 4 * E.kg;
-    float v[NPX][16];
+constexpr int EC_REC = 3 * 64;   // records of one constants buffer: [bias | a | s] x 1 KB (128 floats + pad for the DMA's upper lanes)
+
+template <int NPX, int NROW>   // NPX = 1: one pixel per lane; NPX = 2: the lane owns output px (2X, 2X+1) (sub-pixel upsample kernel)
+__device__ __forceinline__ void epilogue_mtile(const EpiCtx& E, const u32x4* ec, f32x16 (&acc)[NROW][NPX], int mt_local, int mt_global,
+                                               const int (&ys)[NROW], int x, bool x_ok) {
+    // constants of this lane's 16 couts: q = 4 g + i  <->  channel 32 mt + 4 kg + 8 g + i
+    float bq[16], aq[16], sq[16];
+    {
+        const float4* e4 = reinterpret_cast<const float4*>(ec);
+        const int c4 = (mt_local * 32 + 4 * E.kg) >> 2;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int co = cbase + (q & 3) + 8 * (q >> 2);
-        const float bq = P.bias ? P.bias[co] : 0.0f;
-#pragma unroll
-        for (int e = 0; e < NPX; ++e) v[e][q] = acc[e][q] + bq;
-    }
-    const size_t o0 = ((size_t)E.b * P.Cout + cbase) * E.HW + (size_t)y * P.W + x;
-    if (P.res) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const float* rp = P.res + o0 + (size_t)((q & 3) + 8 * (q >> 2)) * E.HW;
-            if (NPX == 2) {
-                const float2 r2 = *reinterpret_cast<const float2*>(rp);
-                v[0][q] += r2.x;
-                v[NPX - 1][q] += r2.y;
-            } else {
-                v[0][q] += *rp;
+        for (int g = 0; g < 4; ++g) {
+            const float4 tb = E.has_bias ? e4[c4 + 2 * g] : make_float4(0.f, 0.f, 0.f, 0.f);
+            bq[4 * g] = tb.x; bq[4 * g + 1] = tb.y; bq[4 * g + 2] = tb.z; bq[4 * g + 3] = tb.w;
+            if (E.has_act) {
+                const float4 ta = e4[64 + c4 + 2 * g], ts = e4[128 + c4 + 2 * g];   // slots of 64 float4 (1 KB)
+                aq[4 * g] = ta.x; aq[4 * g + 1] = ta.y; aq[4 * g + 2] = ta.z; aq[4 * g + 3] = ta.w;
+                sq[4 * g] = ts.x; sq[4 * g + 1] = ts.y; sq[4 * g + 2] = ts.z; sq[4 * g + 3] = ts.w;
             }
         }
     }
-    if (P.y32) {
+    const int cbase = mt_global * 32 + 4 * E.kg;
+    const size_t obase = ((size_t)E.b * E.Cout + cbase) * E.HW;
+    const int xc = x_ok ? x : 0;                                  // clamped column for the unconditional residual loads
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            float* yp = P.y32 + o0 + (size_t)((q & 3) + 8 * (q >> 2)) * E.HW;
-            if (NPX == 2) *reinterpret_cast<float2*>(yp) = make_float2(v[0][q], v[NPX - 1][q]);
-            else *yp = v[0][q];
+    for (int n = 0; n < NROW; ++n)
+#pragma unroll
+        for (int e = 0; e < NPX; ++e)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[n][e][q] += bq[q];
+    if (E.res) {
+        constexpr int RB = NPX == 1 ? 2 : 1;      // rows whose residual is in flight together (32 registers)
+#pragma unroll
+        for (int n0 = 0; n0 < NROW; n0 += RB) {
+            float r[RB][NPX][16];
+#pragma unroll
+            for (int n = 0; n < RB; ++n) {
+                const int yc = ys[n0 + n] < E.H ? ys[n0 + n] : E.H - 1;
+                const float* rp0 = E.res + obase + (size_t)yc * E.W + xc;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float* rp = rp0 + (size_t)((q & 3) + 8 * (q >> 2)) * E.HW;
+                    if (NPX == 2) {
+                        const float2 r2 = *reinterpret_cast<const float2*>(rp);
+                        r[n][0][q] = r2.x;
+                        r[n][NPX - 1][q] = r2.y;
+                    } else {
+                        r[n][0][q] = *rp;
+                    }
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < RB; ++n)
+#pragma unroll
+                for (int e = 0; e < NPX; ++e)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[n0 + n][e][q] += r[n][e][q];
         }
     }
-    if (P.yrec) {
-        if (P.coef) {
-            const float* cf = P.coef + (size_t)E.b * 2 * P.Cout + cbase;
+#pragma unroll
+    for (int n = 0; n < NROW; ++n) {
+        const int y = ys[n];
+        if (!(y < E.H && x_ok)) continue;
+        const size_t o0 = obase + (size_t)y * E.W + x;
+        if (E.y32) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const int cc = (q & 3) + 8 * (q >> 2);
-                const float a = cf[cc], s = cf[P.Cout + cc];
-#pragma unroll
-                for (int e = 0; e < NPX; ++e) v[e][q] = silu_f(fmaf(v[e][q], a, s));
+                float* yp = E.y32 + o0 + (size_t)((q & 3) + 8 * (q >> 2)) * E.HW;
+                if (NPX == 2) *reinterpret_cast<float2*>(yp) = make_float2(acc[n][0][q], acc[n][NPX - 1][q]);
+                else *yp = acc[n][0][q];
             }
         }
-        // records R = 0 (q 0..7) and R = 1 (q 8..15) of this lane: planes ((mt*2 + R)*2 + kg)
-        const int Pn = P.Cout >> 3;
-        u32x4* yb = P.yrec + (size_t)E.b * 2 * Pn * E.planeO;
+        if (E.yrec) {
+            // records R = 0 (q 0..7) and R = 1 (q 8..15) of this lane: planes ((mt*2 + R)*2 + kg)
+            const int Pn = E.Cout >> 3;
+            u32x4* yb = E.yrec + (size_t)E.b * 2 * Pn * E.planeO;
 #pragma unroll
-        for (int R = 0; R < 2; ++R) {
-            const size_t pl = (size_t)((mt_global * 2 + R) * 2 + E.kg) * E.planeO;
+            for (int R = 0; R < 2; ++R) {
+                const size_t pl = (size_t)((mt_global * 2 + R) * 2 + E.kg) * E.planeO;
 #pragma unroll
-            for (int e = 0; e < NPX; ++e) {
-                float t8[8];
+                for (int e = 0; e < NPX; ++e) {
+                    float t8[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) t8[j] = v[e][8 * R + j];
-                u32x4 hi, lo;
-                split8r(t8, hi, lo);
-                const size_t at = pl + (size_t)(y + 1) * E.WpO + (x + e + 1);
-                yb[at] = hi;
-                yb[(size_t)Pn * E.planeO + at] = lo;
-            }
-            // zero border of the record image (this block owns the border cells next to its edge pixels)
-            const u32x4 z = {0u, 0u, 0u, 0u};
-            auto zrec = [&](int py, int px) {
-                const size_t at = pl + (size_t)py * E.WpO + px;
-                yb[at] = z;
-                yb[(size_t)Pn * E.planeO + at] = z;
-            };
-            const bool left = x == 0, right = x + NPX == P.W, top = y == 0, bot = y == P.H - 1;
-            if (left) zrec(y + 1, 0);
-            if (right) zrec(y + 1, P.W + 1);
-            if (top) {
+                    for (int j = 0; j < 8; ++j) {
+                        const float t = acc[n][e][8 * R + j];
+                        t8[j] = E.has_act ? silu_f(fmaf(t, aq[8 * R + j], sq[8 * R + j])) : t;
+                    }
+                    u32x4 hi, lo;
+                    split8r(t8, hi, lo);
+                    const size_t at = pl + (size_t)(y + 1) * E.WpO + (x + e + 1);
+                    yb[at] = hi;
+                    yb[(size_t)Pn * E.planeO + at] = lo;
+                }
+                // zero border of the record image (this block owns the border cells next to its edge pixels)
+                const bool left = x == 0, right = x + NPX == E.W, top = y == 0, bot = y == E.H - 1;
+                if (left || right || top || bot) {
+                    const u32x4 z = {0u, 0u, 0u, 0u};
+                    auto zrec = [&](int py, int px) {
+                        const size_t at = pl + (size_t)py * E.WpO + px;
+                        yb[at] = z;
+                        yb[(size_t)Pn * E.planeO + at] = z;
+                    };
+                    if (left) zrec(y + 1, 0);
+                    if (right) zrec(y + 1, E.W + 1);
+                    if (top) {
 #pragma unroll
-                for (int e = 0; e < NPX; ++e) zrec(0, x + e + 1);
-                if (left) zrec(0, 0);
-                if (right) zrec(0, P.W + 1);
-            }
-            if (bot) {
+                        for (int e = 0; e < NPX; ++e) zrec(0, x + e + 1);
+                        if (left) zrec(0, 0);
+                        if (right) zrec(0, E.W + 1);
+                    }
+                    if (bot) {
 #pragma unroll
-                for (int e = 0; e < NPX; ++e) zrec(P.H + 1, x + e + 1);
-                if (left) zrec(P.H + 1, 0);
-                if (right) zrec(P.H + 1, P.W + 1);
+                        for (int e = 0; e < NPX; ++e) zrec(E.H + 1, x + e + 1);
+                        if (left) zrec(E.H + 1, 0);
+                        if (right) zrec(E.H + 1, E.W + 1);
+                    }
+                }
             }
         }
     }
@@ -195,7 +238,16 @@ struct InStage {
     static constexpr int PW = (DMA + 7) / 8;                    // wave-instructions per wave
 };
 
-// direct 3x3:  MW = 32-cout tiles per wave (2), WM = waves along cout, NROW = pixel rows per wave (4: two half-steps of 2)
+// One unit of work of a persistent block: a (batch sample, pixel tile, cout block) triple.
+struct WorkItem {
+    int b, cb, y0, x0;
+};
+
+// direct 3x3:  MW = 32-cout tiles per wave (2), WM = waves along cout, NROW = pixel rows per wave (4: two half-steps of 2).
+// PERSISTENT: the grid is one block per CU; block i works through items i, i + grid, i + 2 grid, ...  The first operands of
+// the NEXT item (weight chunks 0 and 1, input tile of K-step 0) are DMA'd behind the LAST barrier of the current item's K loop
+// -- their LDS slots are free by then -- so neither the launch gap nor the prologue's HBM round trip shows between items:
+// they run under the last MFMAs and the epilogue.
 template <int MW, int WM, int NROW>
 __global__ __launch_bounds__(512, 2) void k_conv3x3_rec(const ConvRParams P) {
     constexpr int WR = 8 / WM, TH = WR * NROW, MT = MW * WM, HN = NROW / 2;
@@ -204,40 +256,52 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rec(const ConvRParams P) {
     constexpr int W_REC = 2 * 3 * MT * 64;              // [hl][dx][mt][lane]
     constexpr int W_DMA = W_REC / 64;
     constexpr int W_PW = (W_DMA + 7) / 8;
-    __shared__ u32x4 smem[2 * IS::PAD + 3 * W_REC];
+    __shared__ u32x4 smem[2 * IS::PAD + 3 * W_REC + 2 * EC_REC];
     u32x4* const in_l = smem;
     u32x4* const w_l = smem + 2 * IS::PAD;
-
-    // block -> (pixel tile, cout block): XCD = id % 8 keeps all cout blocks of a pixel tile on one L2
-    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
-    const int ptile = (slot / P.NCB) * 8 + xcd, cb = slot % P.NCB;
-    if (ptile >= P.ptiles) return;
-    const int b = blockIdx.y;
-    const int py = ptile / P.PX, px = ptile - py * P.PX;
-    const int y0 = py * TH, x0 = px * 32;
+    u32x4* const ec_l = smem + 2 * IS::PAD + 3 * W_REC;     // per-channel epilogue constants, two buffers (item parity)
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kg = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wr = wave / WM;
     const int Hp = P.H + 2, Wp = P.W + 2, Pn = P.Cin >> 3;
     const size_t plane = (size_t)Hp * Wp;
-    const char* xb = reinterpret_cast<const char*>(P.x + (size_t)b * 2 * Pn * plane);
+
+    // work -> (sample, pixel tile, cout block).  Workgroups go to XCDs round-robin (id % 8) and grid % 8 == 0 whenever a block
+    // sees more than one item, so `work % 8` is this block's XCD for all its items: all cout blocks of a pixel tile stay on one L2.
+    const int per_img = ((P.ptiles + 7) / 8) * 8 * P.NCB, total = per_img * P.B;
+    auto decode = [&](int work, WorkItem& it) -> bool {
+        it.b = work / per_img;
+        const int r = work - it.b * per_img, xcd = r & 7, slot = r >> 3;
+        const int ptile = (slot / P.NCB) * 8 + xcd;
+        it.cb = slot % P.NCB;
+        const int py = ptile / P.PX, px = ptile - py * P.PX;
+        it.y0 = py * TH;
+        it.x0 = px * 32;
+        return ptile < P.ptiles;
+    };
+    auto next_valid = [&](int work, WorkItem& it) -> int {   // first item >= work (stride grid) that is a real tile, or >= total
+        while (work < total && !decode(work, it)) work += gridDim.x;
+        return work;
+    };
 
     // input DMA map: wave-instruction di = wave + 8 i covers LDS records [64 di, 64 di + 64) of a stage; hl = di / HALF_DMA
-    unsigned ioff[IS::PW];   // byte offset inside the (K-step, hl) pair of planes
+    auto make_ioff = [&](const WorkItem& it, unsigned (&ioff)[IS::PW]) {   // byte offsets inside the (K-step, hl) pair of planes
 #pragma unroll
-    for (int i = 0; i < IS::PW; ++i) {
-        const int di = wave + 8 * i;
-        int s = (di % IS::HALF_DMA) * 64 + lane;
-        if (s >= IS::HALF) s = IS::HALF - 1;            // pad lanes shadow the last record (they land in the pad area)
-        const int g = s / (ROWS * COLS), p = s - g * (ROWS * COLS);
-        const int r = p / COLS, c = p - r * COLS;
-        int pr = y0 + r, pc = x0 + c;                   // padded coordinates (image row y0 + r - 1)
-        pr = pr < Hp ? pr : Hp - 1;                     // ragged block edge: clamp onto the zero border
-        pc = pc < Wp ? pc : Wp - 1;
-        ioff[i] = (unsigned)(((size_t)g * plane + (size_t)pr * Wp + pc) * 16);
-    }
-    auto issue_input = [&](int k, int stage) {
+        for (int i = 0; i < IS::PW; ++i) {
+            const int di = wave + 8 * i;
+            int s = (di % IS::HALF_DMA) * 64 + lane;
+            if (s >= IS::HALF) s = IS::HALF - 1;            // pad lanes shadow the last record (they land in the pad area)
+            const int g = s / (ROWS * COLS), p = s - g * (ROWS * COLS);
+            const int r = p / COLS, c = p - r * COLS;
+            int pr = it.y0 + r, pc = it.x0 + c;             // padded coordinates (image row y0 + r - 1)
+            pr = pr < Hp ? pr : Hp - 1;                     // ragged block edge: clamp onto the zero border
+            pc = pc < Wp ? pc : Wp - 1;
+            ioff[i] = (unsigned)(((size_t)g * plane + (size_t)pr * Wp + pc) * 16);
+        }
+    };
+    auto issue_input = [&](const WorkItem& it, const unsigned (&ioff)[IS::PW], int k, int stage) {
+        const char* xb = reinterpret_cast<const char*>(P.x + (size_t)it.b * 2 * Pn * plane);
 #pragma unroll
         for (int i = 0; i < IS::PW; ++i) {
             const int di = wave + 8 * i;
@@ -247,15 +311,25 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rec(const ConvRParams P) {
             }
         }
     };
-    const char* wsrc = reinterpret_cast<const char*>(P.w + (size_t)cb * P.NK * 3 * W_REC);
     const unsigned lane16 = lane * 16;
-    auto issue_weights = [&](int ph, int ring) {
+    auto issue_weights = [&](const WorkItem& it, int ph, int ring) {
+        const char* wsrc = reinterpret_cast<const char*>(P.w + (size_t)it.cb * P.NK * 3 * W_REC);
 #pragma unroll
         for (int i = 0; i < W_PW; ++i)
             if (wave + 8 * i < W_DMA) {
                 const char* base = wsrc + ((size_t)ph * W_REC + (wave + 8 * i) * 64) * 16;
                 dma16(base, lane16, w_l + ring * W_REC + (wave + 8 * i) * 64);
             }
+    };
+
+    // epilogue constants of an item's BM couts: waves 0 / 1 / 2 fetch bias / a / s (512 B each; the upper lanes repeat the
+    // lower ones into the pad half of the 1 KB slot)
+    const unsigned lane16h = (lane & 31) * 16;
+    auto issue_consts = [&](const WorkItem& it, int par) {
+        if (wave == 0 && P.bias) dma16(reinterpret_cast<const char*>(P.bias + it.cb * (MT * 32)), lane16h, ec_l + par * EC_REC);
+        if ((wave == 1 || wave == 2) && P.yrec && P.coef)
+            dma16(reinterpret_cast<const char*>(P.coef + ((size_t)it.b * 2 + (wave - 1)) * P.Cout + it.cb * (MT * 32)), lane16h,
+                  ec_l + par * EC_REC + wave * 64);
     };
 
     bf16x8 fw[2][MW][2];   // [set][m][hl]
@@ -277,134 +351,179 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rec(const ConvRParams P) {
             for (int hl = 0; hl < 2; ++hl) fx[set][n][hl] = __builtin_bit_cast(bf16x8, ist[hl * IS::HALF_PAD + n * COLS]);
     };
 
-    f32x16 acc[MW][NROW];
-#pragma unroll
-    for (int m = 0; m < MW; ++m)
-#pragma unroll
-        for (int n = 0; n < NROW; ++n)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[m][n][q] = 0.0f;
-
+    WorkItem cur, nxt;
+    int work = next_valid(blockIdx.x, cur);
+    if (work >= total) return;
+    unsigned ioff[IS::PW];
+    make_ioff(cur, ioff);
+    issue_input(cur, ioff, 0, 0);
+    issue_weights(cur, 0, 0);
+    issue_weights(cur, 1, 1);
+    issue_consts(cur, 0);
     const int nph = P.NK * 3;
-    issue_input(0, 0);
-    issue_weights(0, 0);
-    issue_weights(1, 1);
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    load_fw(0, 0, 0);
-    load_fx(0, 0, 0, 0, 0);
+    int par = 0;
 
-    // one trip = 2 K-steps = 6 phases = 18 steps = 36 half-steps: ring slot (= dy), input stage (= kk) and both register-set
-    // parities are compile-time constants inside the unrolled body
-    for (int k2 = 0; k2 < P.NK; k2 += 2) {
+    while (true) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces of the item's first operands have landed
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        load_fw(0, 0, 0);
+        load_fx(0, 0, 0, 0, 0);
+        const int work_n = next_valid(work + gridDim.x, nxt);
+        unsigned ioff_n[IS::PW];
+        if (work_n < total) make_ioff(nxt, ioff_n);      // (outside the unrolled K loop: keeps its body under the unroll budget)
+
+        f32x16 acc[MW][NROW][1];
 #pragma unroll
-        for (int t = 0; t < 36; ++t) {
-            const int kk = t / 18, dy = (t / 6) % 3, dx = (t / 2) % 3, h = t & 1;
-            const int k = k2 + kk, ph = k * 3 + dy;
-            const int xs = t & 1, ws = (t >> 1) & 1;
-            // ---- the NEXT half-step's fragments go out first
-            MDT_PIN();
-            if (h == 0) {
-                load_fx(xs ^ 1, kk, dy, dx, 1);
-            } else if (t < 35) {
-                const int t1 = t + 1, kk1 = t1 / 18, dy1 = (t1 / 6) % 3, dx1 = (t1 / 2) % 3;
-                load_fw(ws ^ 1, dy1, dx1);
-                load_fx(xs ^ 1, kk1, dy1, dx1, 0);
-            } else if (k2 + 2 < P.NK) {
-                load_fw(ws ^ 1, 0, 0);
-                load_fx(xs ^ 1, 0, 0, 0, 0);
-            }
-            MDT_PIN();
-            // ---- this half-step's MFMAs: term-major over its accumulators (a dependent MFMA is MW*HN issues away)
+        for (int m = 0; m < MW; ++m)
 #pragma unroll
-            for (int term = 0; term < 3; ++term)
+            for (int n = 0; n < NROW; ++n)
 #pragma unroll
-                for (int n = 0; n < HN; ++n)
+                for (int q = 0; q < 16; ++q) acc[m][n][0][q] = 0.0f;
+
+        // one trip = 2 K-steps = 6 phases = 18 steps = 36 half-steps: ring slot (= dy), input stage (= kk) and both register-set
+        // parities are compile-time constants inside the unrolled body
+        for (int k2 = 0; k2 < P.NK; k2 += 2) {
 #pragma unroll
-                    for (int m = 0; m < MW; ++m)
-                        acc[m][h * HN + n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ws][m][term == 0 ? 1 : 0], fx[xs][n][term == 1 ? 1 : 0],
-                                                                                     acc[m][h * HN + n], 0, 0, 0);   // w_lo x_hi, w_hi x_lo, w_hi x_hi
-            MDT_PIN();
-            if (dx == 0 && h == 1) {
-                // chunk ph+1 (and, one phase after it was issued, the input tile of K-step k+1) went out behind the previous barrier
-                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's share has landed
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-            }
-            // DMA issue of this phase (~10 scalar / VMEM instructions per piece), staggered between the two waves that share a
-            // SIMD (w and w + 4): waves 0-3 right behind the barrier, waves 4-7 one half-step later -- while one of the pair
-            // issues its pieces the other one keeps the matrix pipe fed.
-            // Ring slot of chunk ph+2 = the one chunk ph-1 held: every wave finished reading it before the barrier.
-            if ((dx == 0 && h == 1 && wave < 4) || (dx == 1 && h == 0 && wave >= 4)) {
-                if (ph + 2 < nph) issue_weights(ph + 2, (dy + 2) % 3);
-                if (dy == 0 && k + 1 < P.NK) issue_input(k + 1, (kk + 1) & 1);
+            for (int t = 0; t < 36; ++t) {
+                const int kk = t / 18, dy = (t / 6) % 3, dx = (t / 2) % 3, h = t & 1;
+                const int k = k2 + kk, ph = k * 3 + dy;
+                const int xs = t & 1, ws = (t >> 1) & 1;
+                // ---- the NEXT half-step's fragments go out first
+                MDT_PIN();
+                if (h == 0) {
+                    load_fx(xs ^ 1, kk, dy, dx, 1);
+                } else if (t < 35) {
+                    const int t1 = t + 1, kk1 = t1 / 18, dy1 = (t1 / 6) % 3, dx1 = (t1 / 2) % 3;
+                    load_fw(ws ^ 1, dy1, dx1);
+                    load_fx(xs ^ 1, kk1, dy1, dx1, 0);
+                } else if (k2 + 2 < P.NK) {
+                    load_fw(ws ^ 1, 0, 0);
+                    load_fx(xs ^ 1, 0, 0, 0, 0);
+                }
+                MDT_PIN();
+                // ---- this half-step's MFMAs: term-major over its accumulators (a dependent MFMA is MW*HN issues away)
+#pragma unroll
+                for (int term = 0; term < 3; ++term)
+#pragma unroll
+                    for (int n = 0; n < HN; ++n)
+#pragma unroll
+                        for (int m = 0; m < MW; ++m)
+                            acc[m][h * HN + n][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ws][m][term == 0 ? 1 : 0], fx[xs][n][term == 1 ? 1 : 0],
+                                                                                            acc[m][h * HN + n][0], 0, 0, 0);   // w_lo x_hi, w_hi x_lo, w_hi x_hi
+                MDT_PIN();
+                if (dx == 0 && h == 1) {
+                    // Pieces this wave has in flight, oldest first: weight chunk ph+1 (issued behind the previous barrier) and, at
+                    // dy = 1, the input tile of K-step k+1 issued right after it.  The weights are read from the end of this phase
+                    // on, the input tile only from the end of the dy = 2 phase: at dy = 1 the IS::PW youngest pieces (every wave
+                    // issues exactly that many, IS::DMA % 8 == 0) may stay in flight -- a whole extra phase for their HBM round trip.
+                    static_assert(IS::DMA % 8 == 0 && IS::PW == 5, "the counted wait below assumes 5 input pieces per wave");
+                    if (dy == 1 && k + 1 < P.NK) __builtin_amdgcn_s_waitcnt(0x0F75);   // vmcnt(5)
+                    else __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0)
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                }
+                // DMA issue of this phase (~10 scalar / VMEM instructions per piece), staggered between the two waves that share a
+                // SIMD (w and w + 4): waves 0-3 right behind the barrier, waves 4-7 one half-step later -- while one of the pair
+                // issues its pieces the other one keeps the matrix pipe fed.
+                // Ring slot of chunk ph+2 = the one chunk ph-1 held: every wave finished reading it before the barrier.
+                if ((dx == 0 && h == 1 && wave < 4) || (dx == 1 && h == 0 && wave >= 4)) {
+                    if (ph + 2 < nph) issue_weights(cur, ph + 2, (dy + 2) % 3);
+                    if (dy == 0 && k + 1 < P.NK) issue_input(cur, ioff, k + 1, (kk + 1) & 1);
+                    if (kk == 1 && dy == 2 && k + 1 == P.NK && work_n < total) {
+                        // last phase of the item: ring slots 0 / 1 and input stage 0 are out of use (NK is even) -> the next
+                        // item's first operands go there now and land under the remaining MFMAs and the epilogue
+                        issue_input(nxt, ioff_n, 0, 0);
+                        issue_weights(nxt, 0, 0);
+                        issue_weights(nxt, 1, 1);
+                        issue_consts(nxt, par ^ 1);
+                    }
+                }
             }
         }
+
+        EpiCtx E;
+        E.res = P.res; E.y32 = P.y32; E.yrec = P.yrec;
+        E.has_bias = P.bias != nullptr; E.has_act = P.yrec != nullptr && P.coef != nullptr;
+        E.Cout = P.Cout; E.H = P.H; E.W = P.W; E.b = cur.b; E.kg = kg;
+        E.HW = (size_t)P.H * P.W; E.planeO = plane; E.WpO = Wp;
+        const int x = cur.x0 + l31;
+        int ys[NROW];
+#pragma unroll
+        for (int n = 0; n < NROW; ++n) ys[n] = cur.y0 + wr * NROW + n;
+#pragma unroll
+        for (int m = 0; m < MW; ++m)
+            epilogue_mtile<1, NROW>(E, ec_l + par * EC_REC, acc[m], wm * MW + m, cur.cb * MT + wm * MW + m, ys, x, x < P.W);
+        if (work_n >= total) break;
+        work = work_n;
+        cur = nxt;
+        par ^= 1;
+#pragma unroll
+        for (int i = 0; i < IS::PW; ++i) ioff[i] = ioff_n[i];
     }
-
-    EpiCtx E;
-    E.P = &P; E.b = b; E.kg = kg;
-    E.HW = (size_t)P.H * P.W; E.planeO = plane; E.WpO = Wp;
-    const int x = x0 + l31;
-#pragma unroll
-    for (int m = 0; m < MW; ++m)
-#pragma unroll
-        for (int n = 0; n < NROW; ++n) {
-            const int y = y0 + wr * NROW + n;
-            if (y < P.H && x < P.W) {
-                const f32x16 a1[1] = {acc[m][n]};
-                epilogue_tile<1>(E, a1, cb * MT + wm * MW + m, y, x);
-            }
-        }
 }
 
 // =====================================================================================================================
 // nearest-2x upsample + 3x3 conv in sub-pixel form (four 2x2 convs on the un-upsampled grid, see vae_conv_bf16x3.hip
-// k_upconv_bf16x3 for the derivation).  Block = 128 couts x (8 x 32 INPUT px) of ONE output-row parity a and both column
+// k_upconv_bf16x3 for the derivation).  Item = 128 couts x (8 x 32 INPUT px) of ONE output-row parity a and both column
 // parities bb; phases (K-step k, tap row u); a phase = 4 combo-steps c of 12 MFMAs per wave:
 //     c:  0 (shift s 0, bb 0)   1 (s 1, bb 0)   2 (s 1, bb 1)   3 (s 2, bb 1)        tap column v = s - bb
-// Weight chunk [hl][bb][v][mt][lane] per (a, cb, k, u); ring slot = phase % 3.
+// Weight chunk [hl][bb][v][mt][lane] per (a, cb, k, u) in a 3-slot ring.  Persistent like k_conv3x3_rec; an item has 2 NK
+// phases, which need not be a multiple of 3, so the ring position of an item's first chunk (r0) rotates from item to item:
+// the next item's chunks 0 / 1 go to the two slots the last phase is NOT reading.
 __global__ __launch_bounds__(512, 2) void k_upconv_rec(const ConvRParams P) {
     constexpr int MT = 4, MW = 2, WM = 2, NROW = 2, TH = 8;
     constexpr int ROWS = TH + 2, COLS = 34;
     using IS = InStage<ROWS>;
     constexpr int W_REC = 2 * 2 * 2 * MT * 64, W_DMA = W_REC / 64, W_PW = W_DMA / 8;
-    __shared__ u32x4 smem[2 * IS::PAD + 3 * W_REC];
+    __shared__ u32x4 smem[2 * IS::PAD + 3 * W_REC + 2 * EC_REC];
     u32x4* const in_l = smem;
     u32x4* const w_l = smem + 2 * IS::PAD;
-
-    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
-    const int per = P.NCB * 2;
-    const int ptile = (slot / per) * 8 + xcd, rem = slot % per, cb = rem >> 1, a = rem & 1;
-    if (ptile >= P.ptiles) return;
-    const int b = blockIdx.y;
-    const int py = ptile / P.PX, px = ptile - py * P.PX;
-    const int y0 = py * TH, x0 = px * 32;              // INPUT coordinates
+    u32x4* const ec_l = smem + 2 * IS::PAD + 3 * W_REC;
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kg = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wr = wave / WM;
     const int Hp = P.Hin + 2, Wp = P.Win + 2, Pn = P.Cin >> 3;
     const size_t plane = (size_t)Hp * Wp;
-    const char* xb = reinterpret_cast<const char*>(P.x + (size_t)b * 2 * Pn * plane);
 
-    unsigned ioff[IS::PW];
+    struct Item {
+        int b, cb, a, y0, x0;   // y0, x0: INPUT coordinates
+    };
+    const int per = P.NCB * 2, per_img = ((P.ptiles + 7) / 8) * 8 * per, total = per_img * P.B;
+    auto decode = [&](int work, Item& it) -> bool {
+        it.b = work / per_img;
+        const int r = work - it.b * per_img, xcd = r & 7, slot = r >> 3;
+        const int ptile = (slot / per) * 8 + xcd, rem = slot % per;
+        it.cb = rem >> 1;
+        it.a = rem & 1;
+        const int py = ptile / P.PX, px = ptile - py * P.PX;
+        it.y0 = py * TH;
+        it.x0 = px * 32;
+        return ptile < P.ptiles;
+    };
+    auto next_valid = [&](int work, Item& it) -> int {
+        while (work < total && !decode(work, it)) work += gridDim.x;
+        return work;
+    };
+    auto make_ioff = [&](const Item& it, unsigned (&ioff)[IS::PW]) {
 #pragma unroll
-    for (int i = 0; i < IS::PW; ++i) {
-        const int di = wave + 8 * i;
-        int s = (di % IS::HALF_DMA) * 64 + lane;
-        if (s >= IS::HALF) s = IS::HALF - 1;
-        const int g = s / (ROWS * COLS), p = s - g * (ROWS * COLS);
-        const int r = p / COLS, c = p - r * COLS;
-        int pr = y0 + r, pc = x0 + c;
-        pr = pr < Hp ? pr : Hp - 1;
-        pc = pc < Wp ? pc : Wp - 1;
-        ioff[i] = (unsigned)(((size_t)g * plane + (size_t)pr * Wp + pc) * 16);
-    }
-    auto issue_input = [&](int k, int stage) {
+        for (int i = 0; i < IS::PW; ++i) {
+            const int di = wave + 8 * i;
+            int s = (di % IS::HALF_DMA) * 64 + lane;
+            if (s >= IS::HALF) s = IS::HALF - 1;
+            const int g = s / (ROWS * COLS), p = s - g * (ROWS * COLS);
+            const int r = p / COLS, c = p - r * COLS;
+            int pr = it.y0 + r, pc = it.x0 + c;
+            pr = pr < Hp ? pr : Hp - 1;
+            pc = pc < Wp ? pc : Wp - 1;
+            ioff[i] = (unsigned)(((size_t)g * plane + (size_t)pr * Wp + pc) * 16);
+        }
+    };
+    auto issue_input = [&](const Item& it, const unsigned (&ioff)[IS::PW], int k, int stage) {
+        const char* xb = reinterpret_cast<const char*>(P.x + (size_t)it.b * 2 * Pn * plane);
 #pragma unroll
         for (int i = 0; i < IS::PW; ++i) {
             const int di = wave + 8 * i;
@@ -415,20 +534,26 @@ __global__ __launch_bounds__(512, 2) void k_upconv_rec(const ConvRParams P) {
         }
     };
     const int nph = P.NK * 2;
-    const char* wsrc = reinterpret_cast<const char*>(P.w + ((size_t)a * P.NCB + cb) * nph * W_REC);
     const unsigned lane16 = lane * 16;
-    auto issue_weights = [&](int ph, int ring) {
+    auto issue_weights = [&](const Item& it, int ph, int ring) {
+        const char* wsrc = reinterpret_cast<const char*>(P.w + ((size_t)it.a * P.NCB + it.cb) * nph * W_REC);
 #pragma unroll
         for (int i = 0; i < W_PW; ++i) {
             const char* base = wsrc + ((size_t)ph * W_REC + (wave + 8 * i) * 64) * 16;
             dma16(base, lane16, w_l + ring * W_REC + (wave + 8 * i) * 64);
         }
     };
+    const unsigned lane16h = (lane & 31) * 16;
+    auto issue_consts = [&](const Item& it, int par) {
+        if (wave == 0 && P.bias) dma16(reinterpret_cast<const char*>(P.bias + it.cb * (MT * 32)), lane16h, ec_l + par * EC_REC);
+        if ((wave == 1 || wave == 2) && P.yrec && P.coef)
+            dma16(reinterpret_cast<const char*>(P.coef + ((size_t)it.b * 2 + (wave - 1)) * P.Cout + it.cb * (MT * 32)), lane16h,
+                  ec_l + par * EC_REC + wave * 64);
+    };
 
     bf16x8 fw[2][MW][2];     // [set][m][hl]   weight tiles of one combo-step
     bf16x8 fx[2][NROW][2];   // [set][n][hl]   input rows of one column shift
     const int wfrag = wm * MW * 64 + lane;
-    const int xfrag = (kg * ROWS + wr * NROW + a) * COLS + l31;   // halo row of output row n at tap row u: + (n + u)*COLS
     auto load_fw = [&](int set, int ring, int c) {
         const int bb = c >> 1, v = ((c + 1) >> 1) - bb;           // c: 0 -> (0, 0), 1 -> (0, 1), 2 -> (1, 0), 3 -> (1, 1)
         const u32x4* wst = w_l + ring * W_REC + wfrag;
@@ -437,7 +562,7 @@ __global__ __launch_bounds__(512, 2) void k_upconv_rec(const ConvRParams P) {
 #pragma unroll
             for (int hl = 0; hl < 2; ++hl) fw[set][m][hl] = __builtin_bit_cast(bf16x8, wst[(((hl * 2 + bb) * 2 + v) * MT + m) * 64]);
     };
-    auto load_fx = [&](int set, int stage, int u, int s) {
+    auto load_fx = [&](int set, int xfrag, int stage, int u, int s) {
         const u32x4* ist = in_l + stage * IS::PAD + xfrag + u * COLS + s;
 #pragma unroll
         for (int n = 0; n < NROW; ++n)
@@ -445,88 +570,122 @@ __global__ __launch_bounds__(512, 2) void k_upconv_rec(const ConvRParams P) {
             for (int hl = 0; hl < 2; ++hl) fx[set][n][hl] = __builtin_bit_cast(bf16x8, ist[hl * IS::HALF_PAD + n * COLS]);
     };
 
-    f32x16 acc[2][MW][NROW];   // [bb][m][n]
+    Item cur, nxt;
+    int work = next_valid(blockIdx.x, cur);
+    if (work >= total) return;
+    unsigned ioff[IS::PW];
+    make_ioff(cur, ioff);
+    issue_input(cur, ioff, 0, 0);
+    issue_weights(cur, 0, 0);
+    issue_weights(cur, 1, 1);
+    issue_consts(cur, 0);
+    int par = 0, r0 = 0;       // constants-buffer parity, ring slot of this item's chunk 0
+
+    while (true) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int xfrag = (kg * ROWS + wr * NROW + cur.a) * COLS + l31;   // halo row of output row n at tap row u: + (n + u)*COLS
+        int rs[3];                                                        // ring slot of local phase p: rs[p % 3]
 #pragma unroll
-    for (int bb = 0; bb < 2; ++bb)
+        for (int i = 0; i < 3; ++i) rs[i] = (r0 + i) % 3;
+        load_fw(0, rs[0], 0);
+        load_fx(0, xfrag, 0, 0, 0);
+        const int work_n = next_valid(work + gridDim.x, nxt);
+        unsigned ioff_n[IS::PW];
+        if (work_n < total) make_ioff(nxt, ioff_n);
+        const int r0_n = (r0 + nph) % 3;                                  // = (slot of the last chunk + 1) % 3
+
+        f32x16 acc[MW][NROW][2];   // [m][n][bb]
 #pragma unroll
         for (int m = 0; m < MW; ++m)
 #pragma unroll
             for (int n = 0; n < NROW; ++n)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) acc[bb][m][n][q] = 0.0f;
-
-    issue_input(0, 0);
-    issue_weights(0, 0);
-    issue_weights(1, 1);
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    load_fw(0, 0, 0);
-    load_fx(0, 0, 0, 0);
-
-    // one trip = 3 K-steps = 6 phases = 24 combo-steps: ring slot (phase % 3) and the register sets are compile-time.
-    // fw set = combo-step parity; fx set = parity of the running shift counter 3*phase + s.  NK % 3 != 0: the surplus
-    // K-steps of the last trip are skipped (wave-uniform branch).
-    for (int k3 = 0; k3 < P.NK; k3 += 3) {
+                for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
-        for (int t = 0; t < 24; ++t) {
-            const int pl_ = t >> 2, c = t & 3;                 // local phase 0..5, combo-step
-            const int kk = pl_ >> 1, u = pl_ & 1, s = (c + 1) >> 1, bb = c >> 1;
-            const int k = k3 + kk, ph = k * 2 + u;
-            const int ws = t & 1, xs = (3 * pl_ + s) & 1;
-            if (k < P.NK) {
-                MDT_PIN();
-                if (c < 3) {
-                    load_fw(ws ^ 1, pl_ % 3, c + 1);
-                    if (c != 1) load_fx(xs ^ 1, k & 1, u, s + 1);
-                } else {
-                    const int pl1 = (pl_ + 1) % 6, kk1 = pl1 >> 1, u1 = pl1 & 1;
-                    const int k1 = (pl_ < 5 ? k3 : k3 + 3) + kk1;
-                    if (k1 < P.NK) {
-                        load_fw(ws ^ 1, pl1 % 3, 0);
-                        load_fx(xs ^ 1, k1 & 1, u1, 0);
+                    for (int q = 0; q < 16; ++q) acc[m][n][bb][q] = 0.0f;
+
+        // one trip = 3 K-steps = 6 phases = 24 combo-steps: the register sets are compile-time (fw set = combo-step parity; fx set =
+        // parity of the running shift counter 3*phase + s) and so is the ring index modulo the item's r0.  NK % 3 != 0: the surplus
+        // K-steps of the last trip are skipped (wave-uniform branch).
+        for (int k3 = 0; k3 < P.NK; k3 += 3) {
+#pragma unroll
+            for (int t = 0; t < 24; ++t) {
+                const int pl_ = t >> 2, c = t & 3;                 // local phase 0..5, combo-step
+                const int kk = pl_ >> 1, u = pl_ & 1, s = (c + 1) >> 1, bb = c >> 1;
+                const int k = k3 + kk, ph = k * 2 + u;
+                const int ws = t & 1, xs = (3 * pl_ + s) & 1;
+                if (k < P.NK) {
+                    MDT_PIN();
+                    if (c < 3) {
+                        load_fw(ws ^ 1, rs[pl_ % 3], c + 1);
+                        if (c != 1) load_fx(xs ^ 1, xfrag, k & 1, u, s + 1);
+                    } else {
+                        const int pl1 = (pl_ + 1) % 6, kk1 = pl1 >> 1, u1 = pl1 & 1;
+                        const int k1 = (pl_ < 5 ? k3 : k3 + 3) + kk1;
+                        if (k1 < P.NK) {
+                            load_fw(ws ^ 1, rs[pl1 % 3], 0);
+                            load_fx(xs ^ 1, xfrag, k1 & 1, u1, 0);
+                        }
+                    }
+                    MDT_PIN();
+#pragma unroll
+                    for (int term = 0; term < 3; ++term)
+#pragma unroll
+                        for (int n = 0; n < NROW; ++n)
+#pragma unroll
+                            for (int m = 0; m < MW; ++m)
+                                acc[m][n][bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ws][m][term == 0 ? 1 : 0], fx[xs][n][term == 1 ? 1 : 0],
+                                                                                        acc[m][n][bb], 0, 0, 0);
+                    MDT_PIN();
+                    if (c == 1) {
+                        __builtin_amdgcn_s_waitcnt(0x0F70);
+                        asm volatile("" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        asm volatile("" ::: "memory");
+                    }
+                    // staggered DMA issue (see k_conv3x3_rec): waves 0-3 behind the barrier, waves 4-7 one combo-step later
+                    if ((c == 1 && wave < 4) || (c == 2 && wave >= 4)) {
+                        if (ph + 2 < nph) issue_weights(cur, ph + 2, rs[(pl_ + 2) % 3]);
+                        if (u == 0 && k + 1 < P.NK) issue_input(cur, ioff, k + 1, (k + 1) & 1);
+                        if (ph + 1 == nph && work_n < total) {
+                            // last phase: the two ring slots it does not read and input stage 0 (NK is even: the last K-step sits in
+                            // stage 1) take the next item's first operands
+                            issue_input(nxt, ioff_n, 0, 0);
+                            issue_weights(nxt, 0, r0_n);
+                            issue_weights(nxt, 1, (r0_n + 1) % 3);
+                            issue_consts(nxt, par ^ 1);
+                        }
                     }
                 }
-                MDT_PIN();
-#pragma unroll
-                for (int term = 0; term < 3; ++term)
-#pragma unroll
-                    for (int n = 0; n < NROW; ++n)
-#pragma unroll
-                        for (int m = 0; m < MW; ++m)
-                            acc[bb][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ws][m][term == 0 ? 1 : 0], fx[xs][n][term == 1 ? 1 : 0],
-                                                                                    acc[bb][m][n], 0, 0, 0);
-                MDT_PIN();
-                if (c == 1) {
-                    __builtin_amdgcn_s_waitcnt(0x0F70);
-                    asm volatile("" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    asm volatile("" ::: "memory");
-                }
-                // staggered DMA issue (see k_conv3x3_rec): waves 0-3 behind the barrier, waves 4-7 one combo-step later
-                if ((c == 1 && wave < 4) || (c == 2 && wave >= 4)) {
-                    if (ph + 2 < nph) issue_weights(ph + 2, (pl_ + 2) % 3);
-                    if (u == 0 && k + 1 < P.NK) issue_input(k + 1, (k + 1) & 1);
-                }
             }
         }
-    }
 
-    EpiCtx E;
-    E.P = &P; E.b = b; E.kg = kg;
-    E.HW = (size_t)P.H * P.W; E.planeO = (size_t)(P.H + 2) * (P.W + 2); E.WpO = P.W + 2;
-    const int xi = x0 + l31;
-#pragma unroll
-    for (int m = 0; m < MW; ++m)
+        EpiCtx E;
+        E.res = P.res; E.y32 = P.y32; E.yrec = P.yrec;
+        E.has_bias = P.bias != nullptr; E.has_act = P.yrec != nullptr && P.coef != nullptr;
+        E.Cout = P.Cout; E.H = P.H; E.W = P.W; E.b = cur.b; E.kg = kg;
+        E.HW = (size_t)P.H * P.W; E.planeO = (size_t)(P.H + 2) * (P.W + 2); E.WpO = P.W + 2;
+        const int xi = cur.x0 + l31;
+        int ys[NROW];
 #pragma unroll
         for (int n = 0; n < NROW; ++n) {
-            const int yi = y0 + wr * NROW + n;
-            if (yi < P.Hin && xi < P.Win) {
-                const f32x16 a2[2] = {acc[0][m][n], acc[1][m][n]};
-                epilogue_tile<2>(E, a2, cb * MT + wm * MW + m, 2 * yi + a, 2 * xi);
-            }
+            const int yi = cur.y0 + wr * NROW + n;
+            ys[n] = yi < P.Hin ? 2 * yi + cur.a : P.H;      // rows past the input's last row: marked invalid
         }
+#pragma unroll
+        for (int m = 0; m < MW; ++m)
+            epilogue_mtile<2, NROW>(E, ec_l + par * EC_REC, acc[m], wm * MW + m, cur.cb * MT + wm * MW + m, ys, 2 * xi, xi < P.Win);
+        if (work_n >= total) break;
+        work = work_n;
+        cur = nxt;
+        par ^= 1;
+        r0 = r0_n;
+#pragma unroll
+        for (int i = 0; i < IS::PW; ++i) ioff[i] = ioff_n[i];
+    }
 }
 
 // =====================================================================================================================
@@ -583,6 +742,23 @@ namespace mdt {
 
 size_t conv_bf16x3_direct_records(int cout, int cin);   // vae_conv_bf16x3.hip
 
+// MDTILE_REC_PERSIST=0: one item per block (A/B of the persistent schedule; read per launch so a probe can flip it in-process)
+static bool rec_persistent() {
+    const char* e = getenv("MDTILE_REC_PERSIST");
+    return !(e && e[0] == '0');
+}
+
+static int num_cus() {
+    static const int n = [] {
+        int dev = 0, cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount;
+        return cus;
+    }();
+    return n;
+}
+
 bool conv_rec_supported(int cout, int cin, int ksize) { return ksize == 3 && cin % 32 == 0 && cout % 128 == 0; }
 
 size_t rec_image_bytes(int B, int C, int H, int W) { return (size_t)B * C * (H + 2) * (W + 2) * 4; }
@@ -614,14 +790,18 @@ int conv_rec_launch(const void* d_xrec, const void* d_w_rec, const float* d_bias
         P.w = (const u32x4*)d_w_rec + conv_bf16x3_direct_records(cout, cin);
         P.PX = (P.Win + 31) / 32;
         P.ptiles = P.PX * ((P.Hin + 7) / 8);
-        dim3 grid(((P.ptiles + 7) / 8) * 8 * P.NCB * 2, B), block(512);
+        const long long items = (long long)((P.ptiles + 7) / 8) * 8 * P.NCB * 2 * B;
+        const int cus = num_cus();
+        dim3 grid((unsigned)((items < cus || !rec_persistent()) ? items : cus / 8 * 8)), block(512);
         hipLaunchKernelGGL(k_upconv_rec, grid, block, 0, s, P);
         MDT_LAUNCH_CHECK();
         return MDTILE_OK;
     }
     P.PX = (W + 31) / 32;
     P.ptiles = P.PX * ((H + 15) / 16);
-    dim3 grid(((P.ptiles + 7) / 8) * 8 * P.NCB, B), block(512);
+    const long long items = (long long)((P.ptiles + 7) / 8) * 8 * P.NCB * B;
+    const int cus = num_cus();                    // one block per CU (155 KB LDS, 2 waves per SIMD)
+    dim3 grid((unsigned)((items < cus || !rec_persistent()) ? items : cus / 8 * 8)), block(512);
     hipLaunchKernelGGL((k_conv3x3_rec<2, 2, 4>), grid, block, 0, s, P);
     MDT_LAUNCH_CHECK();
     return MDTILE_OK;

@@ -22,8 +22,11 @@ STAMP = os.path.join(HERE, ".libmdtile.stamp")
 
 # -ffp-contract=off: the blend reproduces eager-torch op-by-op fp32 rounding (see csrc/blend.hip); kernels that
 # want FMAs ask for them explicitly (fmaf / MFMA builtins).
+# -pragma-unroll-threshold: the record conv kernels (csrc/vae_conv_rec.hip) keep two fragment register sets whose indices are
+# compile-time only after their 36- / 24-step K-loop bodies are FULLY unrolled; the default budget (16 K instructions, estimated
+# before constant folding) is too small for that and a partial unroll would turn the register arrays into scratch memory.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-               "-Wall", "-Wno-unused-function"]
+               "-Wall", "-Wno-unused-function", "-mllvm", "-pragma-unroll-threshold=262144"]
 
 
 def _sources():

@@ -59,8 +59,14 @@ for cin, cout, H, W, up in SHAPES:
     t_r32 = timeit(lambda: pc.call_rec(xrec, residual=res, upsample2x=up, want_f32=True))
     t_rrec = timeit(lambda: pc.call_rec(xrec, upsample2x=up, want_f32=False, want_rec=True, rec_coef=coef_out))
     t_both = timeit(lambda: pc.call_rec(xrec, residual=res, upsample2x=up, want_f32=True, want_rec=True, rec_coef=coef_out))
+    os.environ["MDTILE_REC_PERSIST"] = "0"      # A/B in the same process: one item per block instead of the persistent grid
+    t_rrec1 = timeit(lambda: pc.call_rec(xrec, upsample2x=up, want_f32=False, want_rec=True, rec_coef=coef_out))
+    t_both1 = timeit(lambda: pc.call_rec(xrec, residual=res, upsample2x=up, want_f32=True, want_rec=True, rec_coef=coef_out))
+    os.environ["MDTILE_REC_PERSIST"] = "1"
+    t_rrec2 = timeit(lambda: pc.call_rec(xrec, upsample2x=up, want_f32=False, want_rec=True, rec_coef=coef_out))
     line += (f"rec->f32 {t_r32:7.3f} ms {flops / t_r32 * 1e-9:6.1f} TF | rec->rec {t_rrec:7.3f} ms {flops / t_rrec * 1e-9:6.1f} TF | "
-             f"rec->both {t_both:7.3f} ms {flops / t_both * 1e-9:6.1f} TF | prep {t_prep:6.3f} ms")
+             f"rec->both {t_both:7.3f} ms {flops / t_both * 1e-9:6.1f} TF | prep {t_prep:6.3f} ms"
+             f" | 1-item/block: rec->rec {t_rrec1:7.3f} both {t_both1:7.3f} | persistent again rec->rec {t_rrec2:7.3f}")
     ya = pc(x, residual=res, upsample2x=up, pre_gn=None if up else coef_in)
     yb, _ = pc.call_rec(xrec, residual=res, upsample2x=up, want_f32=True)
     line += f" | dev(rec, f32-in) {((ya - yb).abs().max() / ya.abs().max()).item():.1e}"

@@ -19,14 +19,38 @@ from oracle import vae_oracle as vo
 pytestmark = pytest.mark.gpu
 
 
+_orig_conv2d = F.conv2d
+
+
+def _banded_conv2d(x, w, b=None, stride=1, padding=0, dilation=1, groups=1):
+    """F.conv2d for the GPU-side reference.  MIOpen is switched off (see the fixture) and torch's native conv (im2col + rocBLAS
+    sgemm) silently overflows once C*k*k*H*W passes 2^31, so big stride-1 'same' convs are evaluated in horizontal bands with a
+    one-row halo -- exact, rows of a conv are independent."""
+    k = w.shape[-1]
+    same = stride in (1, (1, 1)) and padding in (k // 2, (k // 2, k // 2)) and dilation in (1, (1, 1)) and groups == 1
+    cols = x.shape[1] * k * k * x.shape[2] * x.shape[3]
+    if not (x.is_cuda and same and cols > 2 ** 29):
+        return _orig_conv2d(x, w, b, stride, padding, dilation, groups)
+    H, h = x.shape[2], k // 2
+    band = max(8, (2 ** 28) // (x.shape[1] * k * k * x.shape[3]))
+    outs = []
+    for y0 in range(0, H, band):
+        y1 = min(H, y0 + band)
+        lo, hi = max(0, y0 - h), min(H, y1 + h)
+        xb = F.pad(x[:, :, lo:hi], (h, h, h - (y0 - lo), h - (hi - y1)))
+        outs.append(_orig_conv2d(xb, w, b, 1, 0, 1, 1))
+    return torch.cat(outs, dim=2)
+
+
 @pytest.fixture(autouse=True)
-def _reference_arithmetic():
+def _reference_arithmetic(monkeypatch):
     """The torch side of these tests is the checker, not the thing measured: keep it cheap and predictable.
-    * MIOpen off for the GPU-side reference: a fresh box has no MIOpen kernel cache, every new conv shape would JIT-compile for
-      tens of seconds; torch's native conv (im2col + rocBLAS sgemm, fp32) needs no compilation.
+    * MIOpen off for the GPU-side reference: a fresh box has no MIOpen kernel cache and every new conv shape would JIT-compile
+      for tens of seconds (17 minutes for this file); torch's native fp32 conv needs no compilation (banded, see above).
     * 32 CPU threads for the CPU oracle: eager torch convs on these small tiles are slower on a 256-thread pool."""
     nt = torch.get_num_threads()
     torch.set_num_threads(min(32, nt))
+    monkeypatch.setattr(F, "conv2d", _banded_conv2d)
     with torch.backends.cudnn.flags(enabled=False):
         yield
     torch.set_num_threads(nt)
