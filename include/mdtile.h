@@ -170,6 +170,24 @@ int mdtile_blend_finalize(const mdtile_plan* plan, const mdtile_blend_args* args
 int mdtile_region_noise(float* d_noise, int N, int C, int H, int W, const mdtile_region* regions, int num_regions,
                         mdtile_stream_t stream);
 
+/* Noise Inversion renoise composite (tile_methods/abstractdiffusion.py:651-676, inside sample_img2img):
+ *   d_noise, d_inverse_noise, d_out [N,C,H,W] fp32, d_renoise_mask [H,W] fp32 (already scaled by the renoise strength and clamped).
+ *   num_regions > 0 (the caller passes the custom regions only when the grid is disabled, :658): the job's noise is first re-weighted
+ *   noise' = bg * (1 - fw) + fg * fw with bg = noise where a background region covers the pixel, fg / fw = hit-count averages of
+ *   the noise / of the foreground regions' feather masks (.weight [h,w] fp32; .out unused), in list order.
+ *   out = ((1 - m) * inverse + m * noise') / sqrt(m^2 + (1 - m)^2).   The same fp32 ops in the same order as the eager code, each
+ *   correctly rounded (torch's CPU sqrt is 1 ulp off on ~1 % of inputs: that is the only possible last-bit difference).  <= 16 regions. */
+int mdtile_noise_inverse_blend(const float* d_noise, const float* d_inverse_noise, const float* d_renoise_mask, float* d_out, int N, int C,
+                               int H, int W, const mdtile_region* regions, int num_regions, mdtile_stream_t stream);
+
+/* ControlNet / StableSR tile slicing (tile_methods/abstractdiffusion.py:475-544, 548-588): num_rects (<= 16) rectangles of size w x h
+ * at rects_xy[2 i], rects_xy[2 i + 1] of d_x_in [N,C,H,W] are cut out, concatenated (tile-major, then the N samples: torch.cat over
+ * the bboxes) and repeated `repeat` times for the sampler's cond / uncond copies:
+ *   tile_major = 1: out row j * repeat + r = row j (k-diffusion, :528-533);   tile_major = 0: out row r * (num_rects * N) + j (DDIM, :535).
+ * d_out [num_rects * N * repeat, C, h, w], same dtype.  Pass the latent-grid rectangles multiplied by opt_f = 8 for ControlNet hints. */
+int mdtile_gather_rects(int dtype, int N, int C, int W, int H, const void* d_x_in, const int* rects_xy, int num_rects, int w, int h,
+                        int repeat, int tile_major, void* d_out, mdtile_stream_t stream);
+
 /* ----------------------------------------------------------------------------------------------------------
  * Tiled VAE (scripts/tilevae.py).  All tensors fp32 NCHW.
  * -------------------------------------------------------------------------------------------------------- */
@@ -290,6 +308,34 @@ int mdtile_vae_fast_size(int H, int W, int tile_size, int* oh, int* ow);
 size_t mdtile_vae_fast_ws_size(int C);
 int mdtile_vae_fast_input(const float* d_z, int N, int C, int H, int W, int tile_size, float* d_out, void* d_ws,
                           mdtile_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------------------------
+ * Multi-GPU (upstream is single-device: scripts/tilediffusion.py:257-383 drives one `p`).
+ * A shard context owns one RCCL communicator and one HIP stream per LOCAL rank.  RCCL is dlopen'ed on first use.
+ *   mdtile_shard_init(ndev, dev_ids)      single process, one rank per listed device (ncclCommInitAll): usable from inside a webui.
+ *                                         Listing a device twice (or MDTILE_SHARD_TRANSPORT=copy) selects the "copy" transport:
+ *                                         hipMemcpyAsync + events instead of RCCL, same packing and summation (1-GPU functional runs)
+ *   mdtile_shard_unique_id / _init_rank   one rank of a process-per-GPU job: rank 0 draws the 128-byte id, the host distributes it
+ *   mdtile_shard_info                     info4 = { ranks, local ranks, first local rank, 1 = RCCL | 0 = copy transport }
+ * Per-rank arrays below have one entry per LOCAL rank; streams == NULL uses the context's own streams (mdtile_shard_stream).
+ *   mdtile_halo_exchange   band_rows[2 r], [2 r + 1] = canvas rows [lo, hi) the tiles of rank r touch (contiguous bands of tile rows).
+ *                          d_partial[i] [N,C,H,W] fp32 holds rank i's partial sums (mdtile_blend with MDTILE_BLEND_PARTIAL); rows shared
+ *                          with other bands are packed, swapped (grouped ncclSend / ncclRecv) and summed in ascending rank order on
+ *                          every side (bit-identical everywhere); then mdtile_blend_finalize.  d_scratch[i]: mdtile_halo_scratch_bytes.
+ *   mdtile_allreduce_stats all-reduce(sum) of `count` doubles in place (slow-mode GroupNorm pooling across ranks, tilevae.py:320-335)
+ *   mdtile_shard_bcast     `bytes` from rank `root` to all ranks (a region's model output to the bands that composite it) */
+typedef struct mdtile_shard mdtile_shard;
+mdtile_shard* mdtile_shard_init(int ndev, const int* dev_ids);
+int mdtile_shard_unique_id(void* id128);
+mdtile_shard* mdtile_shard_init_rank(int nranks, int rank, const void* id128, int device);
+void mdtile_shard_destroy(mdtile_shard* sh);
+int mdtile_shard_info(const mdtile_shard* sh, int* info4);
+mdtile_stream_t mdtile_shard_stream(const mdtile_shard* sh, int local_rank);
+size_t mdtile_halo_scratch_bytes(int nranks, int rank, const int* band_rows, int N, int C, int W);
+int mdtile_halo_exchange(mdtile_shard* sh, float* const* d_partial, void* const* d_scratch, int N, int C, int H, int W,
+                         const int* band_rows, const mdtile_stream_t* streams);
+int mdtile_allreduce_stats(mdtile_shard* sh, double* const* d_buf, int count, const mdtile_stream_t* streams);
+int mdtile_shard_bcast(mdtile_shard* sh, void* const* d_buf, size_t bytes, int root, const mdtile_stream_t* streams);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,434 @@
+// Multi-GPU pieces of the hot path behind the C ABI (nothing upstream corresponds to this file -- the
+// reference is single-process / single-device, scripts/tilediffusion.py:257-383 drives ONE `p`).
+//
+// A shard context owns one RCCL communicator + one HIP stream per LOCAL rank:
+//   * mdtile_shard_init(ndev, dev_ids)           single process, one rank per listed device (ncclCommInitAll) -- the form a webui
+//                                                 process can use: the plugin keeps one `p`, the engine spreads the tiles
+//   * mdtile_shard_init_rank(n, rank, id, dev)   one rank of a process-per-GPU job (ncclCommInitRank; bench.py under torchrun)
+// RCCL is dlopen'ed on first use (libmdtile.so itself links no collective library and loads on hosts without RCCL).
+// Transport "copy": when the listed devices repeat (a 1-GPU box exercising the N-rank flow) or MDTILE_SHARD_TRANSPORT=copy, the
+// ranks of a single-process context move their slabs with hipMemcpyAsync + events instead -- same packing, same summation.
+//
+// mdtile_halo_exchange: diffusion tiles are split in contiguous bands of tile rows, one per rank (mdtile/sharding.py).  After a
+// rank accumulated its own tiles (mdtile_blend with MDTILE_BLEND_PARTIAL) only the canvas rows that tiles of two bands touch need
+// another rank's data: each rank packs those `rows x W x N*C` fp32 slabs, swaps them with the peers that share them (grouped
+// ncclSend / ncclRecv: xGMI is point-to-point, two neighbour transfers of ~1 MB beat a ring all-reduce of the 33.5 MB canvas),
+// and k_halo_add sums own + received pieces in ASCENDING RANK ORDER on both sides -> bit-identical sums everywhere.
+#include "common.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <vector>
+
+using namespace mdt;
+
+namespace {
+
+struct Rccl {
+    void* h = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+Rccl* rccl() {
+    static Rccl R;
+    static bool tried = false;
+    if (tried) return R.h ? &R : nullptr;
+    tried = true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"}) {
+        R.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (R.h) break;
+    }
+    if (!R.h) return nullptr;
+#define MDT_SYM(field, sym)                                              \
+    R.field = reinterpret_cast<decltype(R.field)>(dlsym(R.h, sym));      \
+    if (!R.field) { R.h = nullptr; return nullptr; }
+    MDT_SYM(CommInitAll, "ncclCommInitAll")
+    MDT_SYM(CommInitRank, "ncclCommInitRank")
+    MDT_SYM(GetUniqueId, "ncclGetUniqueId")
+    MDT_SYM(CommDestroy, "ncclCommDestroy")
+    MDT_SYM(GroupStart, "ncclGroupStart")
+    MDT_SYM(GroupEnd, "ncclGroupEnd")
+    MDT_SYM(Send, "ncclSend")
+    MDT_SYM(Recv, "ncclRecv")
+    MDT_SYM(AllReduce, "ncclAllReduce")
+    MDT_SYM(Broadcast, "ncclBroadcast")
+    MDT_SYM(GetErrorString, "ncclGetErrorString")
+#undef MDT_SYM
+    return &R;
+}
+
+#define MDT_NCCL(expr)                                                                          \
+    do {                                                                                        \
+        ncclResult_t _r = (expr);                                                               \
+        if (_r != ncclSuccess) {                                                                \
+            mdt::set_error("%s failed: %s (%s:%d)", #expr, rccl()->GetErrorString(_r), __FILE__, __LINE__); \
+            return MDTILE_E_HIP;                                                                \
+        }                                                                                       \
+    } while (0)
+
+// slabs of rows [lo, hi) of every plane of a [planes, H, W] canvas <-> contiguous [planes, hi - lo, W]
+__global__ __launch_bounds__(256) void k_slab_pack(const float* __restrict__ canvas, float* __restrict__ slab, int H, int W, int lo, int rows) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t per = (size_t)rows * W;
+    if (i >= per) return;
+    const int plane = blockIdx.y;
+    slab[(size_t)plane * per + i] = canvas[((size_t)plane * H + lo) * W + i];
+}
+
+constexpr int MAX_HALO_PEERS = 8;
+struct HaloSet {
+    int peer[MAX_HALO_PEERS], lo[MAX_HALO_PEERS], hi[MAX_HALO_PEERS];
+    const float* recv[MAX_HALO_PEERS];     // received slab of that peer: [planes, hi - lo, W]
+    int n;
+};
+
+// canvas rows [row_lo, row_hi): every element shared with peers becomes the sum of all contributions in ascending rank order
+__global__ __launch_bounds__(256) void k_halo_add(float* __restrict__ canvas, int H, int W, int row_lo, int rows, int me, const HaloSet S) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)rows * W) return;
+    const int y = row_lo + (int)(i / W), x = (int)(i % W);
+    const int plane = blockIdx.y;
+    float* p = canvas + ((size_t)plane * H + y) * W + x;
+    float acc = 0.0f;
+    bool first = true, mine_added = false, shared = false;
+    // peers are listed in ascending rank order; the own piece is inserted at its place
+    for (int k = 0; k <= S.n; ++k) {
+        const bool own_turn = !mine_added && (k == S.n || S.peer[k] > me);
+        if (own_turn) {
+            acc = first ? *p : acc + *p;
+            first = false;
+            mine_added = true;
+        }
+        if (k == S.n) break;
+        if (y >= S.lo[k] && y < S.hi[k]) {
+            const float v = S.recv[k][((size_t)plane * (S.hi[k] - S.lo[k]) + (y - S.lo[k])) * W + x];
+            acc = first ? v : acc + v;
+            first = false;
+            shared = true;
+        }
+    }
+    if (shared) *p = acc;
+}
+
+}  // namespace
+
+struct mdtile_shard {
+    int nranks = 0, nlocal = 0, first = 0;     // ranks [first, first + nlocal) live in this process
+    bool copy_transport = false;
+    std::vector<int> dev;                       // device of each LOCAL rank
+    std::vector<ncclComm_t> comm;
+    std::vector<hipStream_t> stream;
+    std::vector<hipEvent_t> ev;                 // copy transport: "slabs of local rank i are packed"
+};
+
+static void shard_free(mdtile_shard* sh) {
+    if (!sh) return;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (int i = 0; i < (int)sh->dev.size(); ++i) {
+        (void)hipSetDevice(sh->dev[i]);
+        if (i < (int)sh->comm.size() && sh->comm[i] && rccl()) rccl()->CommDestroy(sh->comm[i]);
+        if (i < (int)sh->stream.size() && sh->stream[i]) (void)hipStreamDestroy(sh->stream[i]);
+        if (i < (int)sh->ev.size() && sh->ev[i]) (void)hipEventDestroy(sh->ev[i]);
+    }
+    (void)hipSetDevice(cur);
+    delete sh;
+}
+
+static bool make_streams(mdtile_shard* sh) {
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    sh->stream.assign(sh->nlocal, nullptr);
+    sh->ev.assign(sh->nlocal, nullptr);
+    for (int i = 0; i < sh->nlocal; ++i) {
+        if (hipSetDevice(sh->dev[i]) != hipSuccess || hipStreamCreateWithFlags(&sh->stream[i], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&sh->ev[i], hipEventDisableTiming) != hipSuccess) {
+            (void)hipSetDevice(cur);
+            return false;
+        }
+    }
+    (void)hipSetDevice(cur);
+    return true;
+}
+
+extern "C" mdtile_shard* mdtile_shard_init(int ndev, const int* dev_ids) {
+    if (ndev <= 0 || ndev > 64 || !dev_ids) {
+        set_error("mdtile_shard_init: bad arguments ndev=%d", ndev);
+        return nullptr;
+    }
+    auto* sh = new mdtile_shard;
+    sh->nranks = sh->nlocal = ndev;
+    sh->first = 0;
+    sh->dev.assign(dev_ids, dev_ids + ndev);
+    bool repeats = false;
+    for (int i = 0; i < ndev; ++i)
+        for (int j = 0; j < i; ++j) repeats |= dev_ids[i] == dev_ids[j];
+    const char* env = getenv("MDTILE_SHARD_TRANSPORT");
+    sh->copy_transport = repeats || ndev == 1 || (env && strcmp(env, "copy") == 0);
+    if (!make_streams(sh)) {
+        set_error("mdtile_shard_init: stream / event creation failed");
+        shard_free(sh);
+        return nullptr;
+    }
+    if (!sh->copy_transport) {
+        Rccl* R = rccl();
+        if (!R) {
+            set_error("mdtile_shard_init: librccl.so not found (dlopen): %s", dlerror());
+            shard_free(sh);
+            return nullptr;
+        }
+        sh->comm.assign(ndev, nullptr);
+        ncclResult_t r = R->CommInitAll(sh->comm.data(), ndev, dev_ids);
+        if (r != ncclSuccess) {
+            set_error("ncclCommInitAll failed: %s", R->GetErrorString(r));
+            shard_free(sh);
+            return nullptr;
+        }
+    }
+    return sh;
+}
+
+extern "C" int mdtile_shard_unique_id(void* id128) {
+    MDT_CHECK_ARG(id128, "mdtile_shard_unique_id: null argument");
+    Rccl* R = rccl();
+    MDT_CHECK_ARG(R, "mdtile_shard_unique_id: librccl.so not found");
+    ncclUniqueId id;
+    MDT_NCCL(R->GetUniqueId(&id));
+    memcpy(id128, &id, NCCL_UNIQUE_ID_BYTES);
+    return MDTILE_OK;
+}
+
+extern "C" mdtile_shard* mdtile_shard_init_rank(int nranks, int rank, const void* id128, int device) {
+    Rccl* R = rccl();
+    if (nranks <= 0 || rank < 0 || rank >= nranks || !id128 || !R) {
+        set_error("mdtile_shard_init_rank: bad arguments (nranks=%d rank=%d) or librccl.so missing", nranks, rank);
+        return nullptr;
+    }
+    auto* sh = new mdtile_shard;
+    sh->nranks = nranks;
+    sh->nlocal = 1;
+    sh->first = rank;
+    sh->dev.assign(1, device);
+    if (!make_streams(sh)) {
+        set_error("mdtile_shard_init_rank: stream / event creation failed");
+        shard_free(sh);
+        return nullptr;
+    }
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    (void)hipSetDevice(device);
+    ncclUniqueId id;
+    memcpy(&id, id128, NCCL_UNIQUE_ID_BYTES);
+    sh->comm.assign(1, nullptr);
+    ncclResult_t r = R->CommInitRank(&sh->comm[0], nranks, id, rank);
+    (void)hipSetDevice(cur);
+    if (r != ncclSuccess) {
+        set_error("ncclCommInitRank failed: %s", R->GetErrorString(r));
+        shard_free(sh);
+        return nullptr;
+    }
+    return sh;
+}
+
+extern "C" void mdtile_shard_destroy(mdtile_shard* sh) { shard_free(sh); }
+
+extern "C" int mdtile_shard_info(const mdtile_shard* sh, int* info4) {
+    MDT_CHECK_ARG(sh && info4, "mdtile_shard_info: null argument");
+    info4[0] = sh->nranks;
+    info4[1] = sh->nlocal;
+    info4[2] = sh->first;
+    info4[3] = sh->copy_transport ? 0 : 1;
+    return MDTILE_OK;
+}
+
+extern "C" mdtile_stream_t mdtile_shard_stream(const mdtile_shard* sh, int local_rank) {
+    if (!sh || local_rank < 0 || local_rank >= sh->nlocal) return nullptr;
+    return reinterpret_cast<mdtile_stream_t>(sh->stream[local_rank]);
+}
+
+// Canvas rows two bands share; ascending peer order.  band_rows[2 r], band_rows[2 r + 1] = rows [lo, hi) rank r's tiles touch.
+static int halos_of(const int* band_rows, int nranks, int me, HaloSet& S) {
+    S.n = 0;
+    const int mlo = band_rows[2 * me], mhi = band_rows[2 * me + 1];
+    if (mhi <= mlo) return MDTILE_OK;
+    for (int r = 0; r < nranks; ++r) {
+        if (r == me || band_rows[2 * r + 1] <= band_rows[2 * r]) continue;
+        const int lo = mlo > band_rows[2 * r] ? mlo : band_rows[2 * r];
+        const int hi = mhi < band_rows[2 * r + 1] ? mhi : band_rows[2 * r + 1];
+        if (lo >= hi) continue;
+        if (S.n == MAX_HALO_PEERS) {
+            set_error("mdtile_halo_exchange: rank %d shares rows with more than %d bands", me, MAX_HALO_PEERS);
+            return MDTILE_E_LIMIT;
+        }
+        S.peer[S.n] = r; S.lo[S.n] = lo; S.hi[S.n] = hi; S.recv[S.n] = nullptr;
+        ++S.n;
+    }
+    return MDTILE_OK;
+}
+
+extern "C" size_t mdtile_halo_scratch_bytes(int nranks, int rank, const int* band_rows, int N, int C, int W) {
+    HaloSet S;
+    if (!band_rows || rank < 0 || rank >= nranks || halos_of(band_rows, nranks, rank, S) != MDTILE_OK) return 0;
+    size_t floats = 0;
+    for (int k = 0; k < S.n; ++k) floats += (size_t)(S.hi[k] - S.lo[k]) * W * N * C;
+    return 2 * floats * sizeof(float) + 256;    // send + receive copies
+}
+
+extern "C" int mdtile_halo_exchange(mdtile_shard* sh, float* const* d_partial, void* const* d_scratch, int N, int C, int H, int W,
+                                    const int* band_rows, const mdtile_stream_t* streams) {
+    MDT_CHECK_ARG(sh && d_partial && d_scratch && band_rows, "mdtile_halo_exchange: null argument");
+    MDT_CHECK_ARG(N > 0 && C > 0 && N * C <= 65535 && H > 0 && W > 0, "mdtile_halo_exchange: bad shape N=%d C=%d H=%d W=%d", N, C, H, W);
+    const int planes = N * C;
+    int cur = 0;
+    MDT_HIP(hipGetDevice(&cur));
+    std::vector<HaloSet> sets(sh->nlocal);
+    std::vector<std::vector<float*>> sendp(sh->nlocal), recvp(sh->nlocal);
+    // 1. pack
+    for (int i = 0; i < sh->nlocal; ++i) {
+        const int me = sh->first + i;
+        HaloSet& S = sets[i];
+        int rc = halos_of(band_rows, sh->nranks, me, S);
+        if (rc != MDTILE_OK) return rc;
+        hipStream_t st = streams ? as_stream(streams[i]) : sh->stream[i];
+        MDT_HIP(hipSetDevice(sh->dev[i]));
+        float* base = reinterpret_cast<float*>(d_scratch[i]);
+        size_t off = 0;
+        for (int k = 0; k < S.n; ++k) {
+            const size_t n = (size_t)(S.hi[k] - S.lo[k]) * W * planes;
+            sendp[i].push_back(base + off);
+            recvp[i].push_back(base + off + n);
+            S.recv[k] = base + off + n;
+            off += 2 * n;
+            hipLaunchKernelGGL(k_slab_pack, dim3(cdiv((long long)(S.hi[k] - S.lo[k]) * W, 256), planes), dim3(256), 0, st, d_partial[i],
+                               sendp[i][k], H, W, S.lo[k], S.hi[k] - S.lo[k]);
+        }
+        if (sh->copy_transport) MDT_HIP(hipEventRecord(sh->ev[i], st));
+    }
+    MDT_LAUNCH_CHECK();
+    // 2. swap
+    if (sh->copy_transport) {
+        for (int i = 0; i < sh->nlocal; ++i) {
+            hipStream_t st = streams ? as_stream(streams[i]) : sh->stream[i];
+            MDT_HIP(hipSetDevice(sh->dev[i]));
+            for (int k = 0; k < sets[i].n; ++k) {
+                const int j = sets[i].peer[k] - sh->first;          // the peer is local: single-process context
+                MDT_CHECK_ARG(j >= 0 && j < sh->nlocal, "mdtile_halo_exchange: the copy transport needs every rank in this process");
+                int kk = -1;
+                for (int q = 0; q < sets[j].n; ++q)
+                    if (sets[j].peer[q] == sh->first + i) kk = q;
+                MDT_CHECK_ARG(kk >= 0, "mdtile_halo_exchange: asymmetric band table");
+                const size_t bytes = (size_t)(sets[i].hi[k] - sets[i].lo[k]) * W * planes * sizeof(float);
+                MDT_HIP(hipStreamWaitEvent(st, sh->ev[j], 0));
+                MDT_HIP(hipMemcpyAsync(recvp[i][k], sendp[j][kk], bytes, hipMemcpyDeviceToDevice, st));
+            }
+        }
+    } else {
+        Rccl* R = rccl();
+        MDT_NCCL(R->GroupStart());
+        for (int i = 0; i < sh->nlocal; ++i) {
+            hipStream_t st = streams ? as_stream(streams[i]) : sh->stream[i];
+            for (int k = 0; k < sets[i].n; ++k) {
+                const size_t n = (size_t)(sets[i].hi[k] - sets[i].lo[k]) * W * planes;
+                MDT_NCCL(R->Send(sendp[i][k], n, ncclFloat32, sets[i].peer[k], sh->comm[i], st));
+                MDT_NCCL(R->Recv(recvp[i][k], n, ncclFloat32, sets[i].peer[k], sh->comm[i], st));
+            }
+        }
+        MDT_NCCL(R->GroupEnd());
+    }
+    // 3. sum in ascending rank order
+    for (int i = 0; i < sh->nlocal; ++i) {
+        const HaloSet& S = sets[i];
+        if (S.n == 0) continue;
+        hipStream_t st = streams ? as_stream(streams[i]) : sh->stream[i];
+        MDT_HIP(hipSetDevice(sh->dev[i]));
+        int lo = S.lo[0], hi = S.hi[0];
+        for (int k = 1; k < S.n; ++k) {
+            lo = lo < S.lo[k] ? lo : S.lo[k];
+            hi = hi > S.hi[k] ? hi : S.hi[k];
+        }
+        hipLaunchKernelGGL(k_halo_add, dim3(cdiv((long long)(hi - lo) * W, 256), planes), dim3(256), 0, st, d_partial[i], H, W, lo, hi - lo,
+                           sh->first + i, S);
+    }
+    MDT_LAUNCH_CHECK();
+    MDT_HIP(hipSetDevice(cur));
+    return MDTILE_OK;
+}
+
+// all-reduce(sum) of `count` doubles per local rank (slow-mode GroupNorm barrier: [sum px*mean, sum px*var, sum px]; the
+// sequence-parallel estimator's fp64 (sum, sum of squares) pairs).  In place.
+extern "C" int mdtile_allreduce_stats(mdtile_shard* sh, double* const* d_buf, int count, const mdtile_stream_t* streams) {
+    MDT_CHECK_ARG(sh && d_buf && count > 0, "mdtile_allreduce_stats: bad arguments");
+    if (sh->nranks == 1) return MDTILE_OK;
+    if (sh->copy_transport) {
+        // single process, repeated devices: sum on local rank 0's stream in rank order, then copy back
+        int cur = 0;
+        MDT_HIP(hipGetDevice(&cur));
+        std::vector<double> host((size_t)count * sh->nlocal);
+        for (int i = 0; i < sh->nlocal; ++i) {
+            hipStream_t st = streams ? as_stream(streams[i]) : sh->stream[i];
+            MDT_HIP(hipSetDevice(sh->dev[i]));
+            MDT_HIP(hipMemcpyAsync(host.data() + (size_t)i * count, d_buf[i], count * sizeof(double), hipMemcpyDeviceToHost, st));
+            MDT_HIP(hipStreamSynchronize(st));
+        }
+        for (int c = 0; c < count; ++c) {
+            double a = 0.0;
+            for (int i = 0; i < sh->nlocal; ++i) a += host[(size_t)i * count + c];
+            host[c] = a;
+        }
+        for (int i = 0; i < sh->nlocal; ++i) {
+            hipStream_t st = streams ? as_stream(streams[i]) : sh->stream[i];
+            MDT_HIP(hipSetDevice(sh->dev[i]));
+            MDT_HIP(hipMemcpyAsync(d_buf[i], host.data(), count * sizeof(double), hipMemcpyHostToDevice, st));
+            MDT_HIP(hipStreamSynchronize(st));
+        }
+        MDT_HIP(hipSetDevice(cur));
+        return MDTILE_OK;
+    }
+    Rccl* R = rccl();
+    MDT_NCCL(R->GroupStart());
+    for (int i = 0; i < sh->nlocal; ++i)
+        MDT_NCCL(R->AllReduce(d_buf[i], d_buf[i], count, ncclFloat64, ncclSum, sh->comm[i], streams ? as_stream(streams[i]) : sh->stream[i]));
+    MDT_NCCL(R->GroupEnd());
+    return MDTILE_OK;
+}
+
+// broadcast `bytes` from rank `root` to every rank (a region's model output to the bands that composite it, cfg5)
+extern "C" int mdtile_shard_bcast(mdtile_shard* sh, void* const* d_buf, size_t bytes, int root, const mdtile_stream_t* streams) {
+    MDT_CHECK_ARG(sh && d_buf && root >= 0 && root < sh->nranks, "mdtile_shard_bcast: bad arguments");
+    if (sh->nranks == 1 || bytes == 0) return MDTILE_OK;
+    if (sh->copy_transport) {
+        const int jr = root - sh->first;
+        MDT_CHECK_ARG(jr >= 0 && jr < sh->nlocal, "mdtile_shard_bcast: the copy transport needs every rank in this process");
+        int cur = 0;
+        MDT_HIP(hipGetDevice(&cur));
+        hipStream_t sr = streams ? as_stream(streams[jr]) : sh->stream[jr];
+        MDT_HIP(hipSetDevice(sh->dev[jr]));
+        MDT_HIP(hipEventRecord(sh->ev[jr], sr));
+        for (int i = 0; i < sh->nlocal; ++i) {
+            if (i == jr) continue;
+            hipStream_t st = streams ? as_stream(streams[i]) : sh->stream[i];
+            MDT_HIP(hipSetDevice(sh->dev[i]));
+            MDT_HIP(hipStreamWaitEvent(st, sh->ev[jr], 0));
+            MDT_HIP(hipMemcpyAsync(d_buf[i], d_buf[jr], bytes, hipMemcpyDeviceToDevice, st));
+        }
+        MDT_HIP(hipSetDevice(cur));
+        return MDTILE_OK;
+    }
+    Rccl* R = rccl();
+    MDT_NCCL(R->GroupStart());
+    for (int i = 0; i < sh->nlocal; ++i)
+        MDT_NCCL(R->Broadcast(d_buf[i], d_buf[i], bytes, ncclUint8, root, sh->comm[i], streams ? as_stream(streams[i]) : sh->stream[i]));
+    MDT_NCCL(R->GroupEnd());
+    return MDTILE_OK;
+}

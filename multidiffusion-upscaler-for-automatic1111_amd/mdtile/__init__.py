@@ -69,6 +69,18 @@ _SIGNATURES = {
     "mdtile_blend": (c_int, [c_void_p, POINTER(_BlendArgs), POINTER(c_void_p), c_int, POINTER(_Region), c_int, c_void_p]),
     "mdtile_blend_finalize": (c_int, [c_void_p, POINTER(_BlendArgs), c_void_p, POINTER(_Region), c_int, c_void_p]),
     "mdtile_region_noise": (c_int, [c_void_p, c_int, c_int, c_int, c_int, POINTER(_Region), c_int, c_void_p]),
+    "mdtile_noise_inverse_blend": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, POINTER(_Region), c_int, c_void_p]),
+    "mdtile_gather_rects": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, _IP, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "mdtile_shard_init": (c_void_p, [c_int, _IP]),
+    "mdtile_shard_unique_id": (c_int, [c_void_p]),
+    "mdtile_shard_init_rank": (c_void_p, [c_int, c_int, c_void_p, c_int]),
+    "mdtile_shard_destroy": (None, [c_void_p]),
+    "mdtile_shard_info": (c_int, [c_void_p, _IP]),
+    "mdtile_shard_stream": (c_void_p, [c_void_p, c_int]),
+    "mdtile_halo_scratch_bytes": (c_size_t, [c_int, c_int, _IP, c_int, c_int, c_int]),
+    "mdtile_halo_exchange": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_int, c_int, c_int, c_int, _IP, POINTER(c_void_p)]),
+    "mdtile_allreduce_stats": (c_int, [c_void_p, POINTER(c_void_p), c_int, POINTER(c_void_p)]),
+    "mdtile_shard_bcast": (c_int, [c_void_p, POINTER(c_void_p), c_size_t, c_int, POINTER(c_void_p)]),
     "mdtile_vae_split_tiles": (c_int, [c_int, c_int, c_int, c_int, _IP, _IP, c_int]),
     "mdtile_gn_stats_ws_size": (c_size_t, [c_int, c_int]),
     "mdtile_gn_stats": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -259,6 +271,44 @@ def region_noise(noise: torch.Tensor, regions) -> torch.Tensor:
         arr[i] = _Region(int(x), int(y), int(w), int(h), int(mode), 0, rand.data_ptr(), None)
     _check(lib().mdtile_region_noise(_p(noise), N, C, H, W, arr, len(regions), _stream()), "mdtile_region_noise")
     return noise
+
+
+def noise_inverse_blend(noise: torch.Tensor, inverse_noise: torch.Tensor, renoise_mask: torch.Tensor, regions=()) -> torch.Tensor:
+    """Renoise composite of Noise Inversion (abstractdiffusion.py:651-676).  noise / inverse_noise [N,C,H,W] fp32, renoise_mask
+    [H,W] fp32; regions: [(x, y, w, h, mode, feather [h,w] fp32 or None)] -- pass them only when the grid is disabled (:658)."""
+    _dev_tensor(noise, "noise", torch.float32)
+    _dev_tensor(inverse_noise, "inverse_noise", torch.float32)
+    _dev_tensor(renoise_mask, "renoise_mask", torch.float32)
+    N, C, H, W = noise.shape
+    assert inverse_noise.shape == noise.shape and tuple(renoise_mask.shape) == (H, W)
+    arr = (_Region * max(1, len(regions)))()
+    keep = []
+    for i, (x, y, w, h, mode, feather) in enumerate(regions):
+        fp = 0
+        if feather is not None:
+            _dev_tensor(feather, f"regions[{i}].feather", torch.float32)
+            assert feather.numel() == w * h
+            keep.append(feather)
+            fp = feather.data_ptr()
+        arr[i] = _Region(int(x), int(y), int(w), int(h), int(mode), 0, None, fp)
+    out = torch.empty_like(noise)
+    _check(lib().mdtile_noise_inverse_blend(_p(noise), _p(inverse_noise), _p(renoise_mask), _p(out), N, C, H, W, arr, len(regions), _stream()),
+           "mdtile_noise_inverse_blend")
+    return out
+
+
+def gather_rects(x_in: torch.Tensor, rects_xy: Sequence[Tuple[int, int]], w: int, h: int, repeat: int = 1, tile_major: bool = True) -> torch.Tensor:
+    """cat([x_in[:, :, y:y+h, x:x+w] for (x, y) in rects_xy]) repeated for the sampler's batch copies in one launch
+    (ControlNet / StableSR tile slicing, abstractdiffusion.py:475-544, 548-588).  tile_major: every row's copies are consecutive
+    (k-diffusion); else the whole batch is repeated (DDIM)."""
+    _dev_tensor(x_in, "x_in")
+    N, C, H, W = x_in.shape
+    n = len(rects_xy)
+    flat = (c_int * (2 * n))(*[int(v) for xy in rects_xy for v in xy])
+    out = torch.empty((n * N * repeat, C, h, w), dtype=x_in.dtype, device=x_in.device)
+    _check(lib().mdtile_gather_rects(dtype_code(x_in.dtype), N, C, W, H, _p(x_in), flat, n, int(w), int(h), int(repeat), int(tile_major),
+                                     _p(out), _stream()), "mdtile_gather_rects")
+    return out
 
 
 def reciprocal(x: torch.Tensor) -> torch.Tensor:
@@ -679,3 +729,78 @@ def vae_fast_input(z: torch.Tensor, tile_size: int) -> torch.Tensor:
     ws = torch.empty((lib().mdtile_vae_fast_ws_size(C) + 7) // 8, dtype=torch.float64, device=z.device)
     _check(lib().mdtile_vae_fast_input(_p(z), N, C, H, W, int(tile_size), _p(out), _p(ws), _stream()), "mdtile_vae_fast_input")
     return out
+
+
+# ---- multi-GPU -------------------------------------------------------------------------------------------------------
+class Shard:
+    """Shard context of the C ABI (include/mdtile.h "Multi-GPU"): one RCCL communicator + one stream per local rank.
+    Shard(dev_ids=[0, 1, ...])            single process, one rank per device (the form usable inside a webui process)
+    Shard(nranks=N, rank=r, uid=bytes)    one rank of a process-per-GPU job; uid = Shard.unique_id() of rank 0, distributed by the host"""
+
+    def __init__(self, dev_ids: Optional[Sequence[int]] = None, nranks: int = 0, rank: int = 0, uid: Optional[bytes] = None,
+                 device: Optional[int] = None):
+        L = lib()
+        if dev_ids is not None:
+            arr = (c_int * len(dev_ids))(*[int(d) for d in dev_ids])
+            self._h = L.mdtile_shard_init(len(dev_ids), arr)
+            self.devices = [int(d) for d in dev_ids]
+        else:
+            assert uid is not None and len(uid) == 128
+            dev = torch.cuda.current_device() if device is None else int(device)
+            self._uid = ctypes.create_string_buffer(bytes(uid), 128)
+            self._h = L.mdtile_shard_init_rank(int(nranks), int(rank), self._uid, dev)
+            self.devices = [dev]
+        if not self._h:
+            raise MdtileError("mdtile_shard_init: " + L.mdtile_last_error().decode(errors="replace"))
+        info = (c_int * 4)()
+        _check(L.mdtile_shard_info(self._h, info), "mdtile_shard_info")
+        self.nranks, self.nlocal, self.first, self.rccl = info[0], info[1], info[2], bool(info[3])
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = ctypes.create_string_buffer(128)
+        _check(lib().mdtile_shard_unique_id(buf), "mdtile_shard_unique_id")
+        return buf.raw
+
+    def _streams(self, streams):
+        if streams is None:
+            return None
+        return (c_void_p * self.nlocal)(*[int(s) for s in streams])
+
+    def stream(self, local_rank: int) -> int:
+        return int(lib().mdtile_shard_stream(self._h, int(local_rank)) or 0)
+
+    def halo_scratch(self, band_rows: Sequence[int], N: int, C: int, W: int) -> List[torch.Tensor]:
+        """One scratch buffer per local rank for halo_exchange (send + receive copies of the shared slabs)."""
+        arr = (c_int * len(band_rows))(*[int(v) for v in band_rows])
+        out = []
+        for i, dev in enumerate(self.devices):
+            n = lib().mdtile_halo_scratch_bytes(self.nranks, self.first + i, arr, N, C, W)
+            out.append(torch.empty(max(1, n // 4), dtype=torch.float32, device=torch.device("cuda", dev)))
+        return out
+
+    def halo_exchange(self, partials: Sequence[torch.Tensor], scratch: Sequence[torch.Tensor], band_rows: Sequence[int], streams=None) -> None:
+        """In place: every partial canvas ([N,C,H,W] fp32, one per local rank) becomes complete on the rows its band touches."""
+        assert len(partials) == self.nlocal == len(scratch)
+        N, C, H, W = partials[0].shape
+        for t in partials:
+            _dev_tensor(t, "partial", torch.float32)
+        pp = (c_void_p * self.nlocal)(*[t.data_ptr() for t in partials])
+        ss = (c_void_p * self.nlocal)(*[t.data_ptr() for t in scratch])
+        arr = (c_int * len(band_rows))(*[int(v) for v in band_rows])
+        _check(lib().mdtile_halo_exchange(self._h, pp, ss, N, C, H, W, arr, self._streams(streams)), "mdtile_halo_exchange")
+
+    def allreduce_stats(self, bufs: Sequence[torch.Tensor], streams=None) -> None:
+        for t in bufs:
+            _dev_tensor(t, "buf", torch.float64)
+        pp = (c_void_p * self.nlocal)(*[t.data_ptr() for t in bufs])
+        _check(lib().mdtile_allreduce_stats(self._h, pp, bufs[0].numel(), self._streams(streams)), "mdtile_allreduce_stats")
+
+    def bcast(self, bufs: Sequence[torch.Tensor], root: int, streams=None) -> None:
+        pp = (c_void_p * self.nlocal)(*[t.data_ptr() for t in bufs])
+        _check(lib().mdtile_shard_bcast(self._h, pp, bufs[0].numel() * bufs[0].element_size(), int(root), self._streams(streams)), "mdtile_shard_bcast")
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.mdtile_shard_destroy(h)

@@ -158,6 +158,9 @@ def estimate_group_norm_sp(steps: Sequence, zs: torch.Tensor, comm: BandComm, op
 
     for pc, s in enumerate(steps):
         if s.kind == "store_res":
+            if s.conv is not None and ops.ksize(s.conv) == 3 and not halo_ok:    # 3x3 conv_shortcut reads the neighbours' rows too
+                comm.exchange_halos(x, ht, hb, rows)
+                halo_ok = True
             res.append(x if s.conv is None else ops.conv(s.conv, x))
         elif s.kind == "norm":
             C = x.shape[1]

@@ -89,7 +89,9 @@ def exchange_and_sum(partial: torch.Tensor, bands: Sequence[Band], rank: int, gr
     halos = halo_rows(bands, rank)
     if not halos:
         return partial
-    # RCCL ("nccl") moves device memory directly; a backend that cannot (gloo: CPU tests, single-GPU multi-process checks)
+    if _CTX is not None and partial.is_cuda and group is None:
+        return exchange_and_sum_ctx(partial, bands)      # C ABI: pack -> ncclSend / ncclRecv -> k_halo_add
+    # torch.distributed path (CPU tests over gloo, single-GPU multi-process checks).  RCCL ("nccl") moves device memory directly; a backend that cannot (gloo: CPU tests, single-GPU multi-process checks)
     # gets the slabs staged through the host
     staged = partial.is_cuda and dist.get_backend(group) == "gloo"
     send = {peer: partial[:, :, lo:hi, :].contiguous() for peer, lo, hi in halos}
@@ -140,3 +142,170 @@ def allreduce_stats(sum_mean_px: torch.Tensor, sum_var_px: torch.Tensor, px: tor
     n = sum_mean_px.numel()
     total = buf[2 * n]
     return (buf[n:2 * n] / total).view_as(sum_var_px), (buf[:n] / total).view_as(sum_mean_px)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# C-ABI shard context (include/mdtile.h "Multi-GPU"): the halo exchange as pack -> grouped ncclSend / ncclRecv -> fixed-order
+# k_halo_add, three launches per evaluation instead of the eager slab arithmetic of exchange_and_sum above.
+# ---------------------------------------------------------------------------------------------------------------------
+_CTX = None          # mdtile.Shard of THIS process when it is one rank of a process-per-GPU job
+_CTX_SCRATCH = {}
+
+
+def init_process_context(rank: int, world: int, device: int, group=None):
+    """One rank per process (bench.py under torchrun): rank 0 draws the RCCL unique id, torch.distributed carries it to the
+    others, every rank joins the communicator through the C ABI.  Afterwards exchange_and_sum / allreduce_stats run on it."""
+    global _CTX
+    import mdtile
+    box = [mdtile.Shard.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    _CTX = mdtile.Shard(nranks=world, rank=rank, uid=box[0], device=device)
+    return _CTX
+
+
+def band_rows_table(bands: Sequence[Band]) -> List[int]:
+    out = []
+    for b in bands:
+        out += [b.row_lo, b.row_hi] if not b.empty else [0, 0]
+    return out
+
+
+def exchange_and_sum_ctx(partial: torch.Tensor, bands: Sequence[Band], ctx=None) -> torch.Tensor:
+    """exchange_and_sum on a shard context holding ONE local rank (this process): in place, on torch's current stream."""
+    ctx = ctx or _CTX
+    table = band_rows_table(bands)
+    key = (tuple(table), tuple(partial.shape), partial.device.index)
+    if key not in _CTX_SCRATCH:
+        _CTX_SCRATCH.clear()
+        _CTX_SCRATCH[key] = ctx.halo_scratch(table, partial.shape[0], partial.shape[1], partial.shape[3])
+    ctx.halo_exchange([partial], _CTX_SCRATCH[key], table, streams=[torch.cuda.current_stream(partial.device).cuda_stream])
+    return partial
+
+
+class ShardedBlend:
+    """One model evaluation (tile gather + overlap blend) split in row bands over the ranks of a mdtile.Shard -- all of them in
+    this process (`mdtile.Shard(dev_ids=[...])`, the form a webui can use) or one per process.  Regions (BASELINE cfg5: region
+    prompt control on 2 GPUs) are dealt round-robin to the ranks: the owner evaluates the region, its output is broadcast to the
+    bands; a background region is ACCUMULATED only by the rank that owns the canvas row (its rows are cut out of the region output,
+    so the shared rows are not counted twice), a foreground region is composited by every rank on the rows it finalises.
+
+        sb = ShardedBlend(shard, W, H, tile_w, tile_h, overlap, tile_bs, method, regions=[(x, y, w, h, mode, feather_ratio)])
+        outs = sb.step(xs, tile_fn, region_fn)      xs / outs: one [N, C, H, W] canvas per LOCAL rank, on that rank's device
+    After step() canvas i is complete on the rows band i touches (what its tiles need for the next evaluation); allgather_rows()
+    completes all of them (single-process contexts)."""
+
+    def __init__(self, shard, W: int, H: int, tile_w: int, tile_h: int, overlap: int, tile_bs: int, method: int, regions=()):
+        import mdtile
+        self.E, self.shard, self.method, self.W, self.H = mdtile, shard, method, W, H
+        self.regions = list(regions)
+        self.local = []
+        for i, dev in enumerate(shard.devices):
+            with torch.cuda.device(dev):
+                d = torch.device("cuda", dev)
+                plan = mdtile.Plan(W, H, tile_w, tile_h, overlap, tile_bs)
+                weights = torch.zeros(1, 1, H, W, device=d)
+                tile_wt = mdtile.gaussian_weights(plan.tile_w, plan.tile_h, d) if method == mdtile.METHOD_MOD else None
+                mdtile.weight_map_add_grid(plan, tile_wt, weights)
+                rw = []       # per region: MoD background weight map / feather mask on this device
+                for (x, y, w, h, mode, fr) in self.regions:
+                    if mode == mdtile.REGION_BG:
+                        cw = mdtile.gaussian_weights(w, h, d) if method == mdtile.METHOD_MOD else None
+                        mdtile.weight_map_add_rect(weights, x, y, w, h, cw, 1.0)
+                        rw.append(cw)
+                    else:
+                        rw.append(mdtile.feather_mask(w, h, fr, d))
+                rescale = None
+                if method == mdtile.METHOD_MOD:
+                    rescale = mdtile.reciprocal(weights)
+                    for k, (x, y, w, h, mode, fr) in enumerate(self.regions):
+                        if mode == mdtile.REGION_BG:
+                            mdtile.rect_mul_canvas(rw[k], rescale, x, y, w, h)
+                self.local.append(dict(dev=d, plan=plan, weights=weights, tile_wt=tile_wt, rescale=rescale, rw=rw, partial=None, out=None, packed=None))
+        plan0 = self.local[0]["plan"]
+        ys = sorted(set(b[1] for b in plan0.bboxes))
+        self.bands = band_partition(ys, plan0.tile_h, plan0.cols, H, shard.nranks)
+        self.table = band_rows_table(self.bands)
+        self.scratch = None
+
+    def _stream(self, i):
+        return torch.cuda.current_stream(self.local[i]["dev"]).cuda_stream
+
+    def region_owner(self, k: int) -> int:
+        return k % self.shard.nranks
+
+    def step(self, xs, tile_fn, region_fn=None):
+        E, sh = self.E, self.shard
+        N, C = xs[0].shape[:2]
+        if self.scratch is None:
+            self.scratch = sh.halo_scratch(self.table, N, C, self.W)
+        # 1. regions: evaluated by their owner, broadcast to every rank
+        routs = [[None] * len(self.regions) for _ in self.local]
+        for k, (x, y, w, h, mode, fr) in enumerate(self.regions):
+            bufs = []
+            for i, L in enumerate(self.local):
+                with torch.cuda.device(L["dev"]):
+                    if sh.first + i == self.region_owner(k):
+                        t = region_fn(E.gather_rect(xs[i].contiguous(), x, y, w, h), k).to(xs[i].dtype).contiguous()
+                    else:
+                        t = torch.empty((N, C, h, w), dtype=xs[i].dtype, device=L["dev"])
+                    bufs.append(t)
+                    routs[i][k] = t
+            sh.bcast(bufs, self.region_owner(k), streams=[self._stream(i) for i in range(len(self.local))])
+        # 2. per rank: gather its tiles, evaluate, accumulate partial sums on the rows they touch
+        for i, L in enumerate(self.local):
+            band = self.bands[sh.first + i]
+            with torch.cuda.device(L["dev"]):
+                x = xs[i].contiguous()
+                plan = L["plan"]
+                if L["partial"] is None:
+                    L["partial"] = torch.zeros(N, C, self.H, self.W, device=L["dev"])
+                    L["out"] = torch.empty(N, C, self.H, self.W, dtype=x.dtype, device=L["dev"])
+                    L["packed"] = torch.zeros(plan.num_tiles * N, C, plan.tile_h, plan.tile_w, dtype=x.dtype, device=L["dev"])
+                if band.empty:
+                    continue
+                E.gather_range(plan, x, L["packed"], band.tile_lo, band.tile_hi)
+                rows = slice(band.tile_lo * N, band.tile_hi * N)
+                L["packed"][rows] = tile_fn(L["packed"][rows]).to(x.dtype)
+                specs = []
+                for k, (rx, ry, rw_, rh, mode, fr) in enumerate(self.regions):
+                    if mode != E.REGION_BG:
+                        continue
+                    lo, hi = max(ry, band.own_lo), min(ry + rh, band.own_hi)       # accumulate a background region once: on OWNED rows
+                    if lo >= hi:
+                        continue
+                    sub = E.gather_rect(routs[i][k], 0, lo - ry, rw_, hi - lo)
+                    wsub = None
+                    if self.method == E.METHOD_MOD:
+                        wsub = L["rw"][k][lo - ry:hi - ry].contiguous()
+                    specs.append(E.RegionSpec(rx, lo, rw_, hi - lo, E.REGION_BG, sub, wsub))
+                kw = dict(weights=L["weights"]) if self.method == E.METHOD_MD else dict(tile_w=L["tile_wt"], rescale=L["rescale"])
+                E.blend(plan, self.method, [L["packed"]], N, C, out=L["partial"], packed=True, partial=True, regions=specs,
+                        tile_range=(band.tile_lo, band.tile_hi), row_range=(band.row_lo, band.row_hi), **kw)
+        # 3. rows shared by two bands: swap + sum in rank order (C ABI: pack, ncclSend / ncclRecv, k_halo_add)
+        sh.halo_exchange([L["partial"] for L in self.local], self.scratch, self.table, streams=[self._stream(i) for i in range(len(self.local))])
+        # 4. epilogue on the band's rows: MD division, foreground composite
+        outs = []
+        for i, L in enumerate(self.local):
+            band = self.bands[sh.first + i]
+            with torch.cuda.device(L["dev"]):
+                if not band.empty:
+                    fg = [E.RegionSpec(rx, ry, rw_, rh, E.REGION_FG, routs[i][k], L["rw"][k])
+                          for k, (rx, ry, rw_, rh, mode, fr) in enumerate(self.regions) if mode == E.REGION_FG]
+                    E.blend_finalize(L["plan"], self.method, L["partial"], weights=L["weights"] if self.method == E.METHOD_MD else None,
+                                     regions=fg, out=L["out"], dtype=L["out"].dtype, row_range=(band.row_lo, band.row_hi))
+                outs.append(L["out"])
+        return outs
+
+    def allgather_rows(self, outs):
+        """Single-process contexts: copy every band's OWNED rows to the other local canvases (peer copies over xGMI)."""
+        assert self.shard.nlocal == self.shard.nranks, "allgather_rows needs every rank in this process"
+        for i, L in enumerate(self.local):
+            b = self.bands[i]
+            if b.empty:
+                continue
+            for j in range(len(self.local)):
+                if j != i:
+                    outs[j][:, :, b.own_lo:b.own_hi].copy_(outs[i][:, :, b.own_lo:b.own_hi], non_blocking=True)
+        for L in self.local:
+            torch.cuda.current_stream(L["dev"]).synchronize()
+        return outs

@@ -8,8 +8,9 @@ stash originals (`create_sampler_original_md`, `apply_model_original_md`), the "
 in-place restore of `p.width/height` in `postprocess`.
 
 Per-region seeds (`processing.create_random_tensors` hijack, upstream :376-383, :486-529) run on the engine
-(`mdtile_region_noise`).  Not carried over (out of the engine's scope, they arm nothing here and only print a notice):
-Noise Inversion, ControlNet / StableSR tensor tiling and the region-config file dialog.
+(`mdtile_region_noise`); Noise Inversion (:431-450, renoise composite on `mdtile_noise_inverse_blend`) and the ControlNet /
+StableSR tensor tiling (:344-361, `mdtile_gather_rects`) are armed exactly where upstream arms them.  Not carried over: the
+region-config file dialog (UI only).
 """
 from __future__ import annotations
 
@@ -121,41 +122,82 @@ class Script(scripts.Script):
         if not enabled:
             return
 
+        # canvas size bookkeeping: stash the originals unconditionally, postprocess restores them (upstream :272-306, :396-402)
+        if hasattr(p, "init_images"):
+            p.init_images_original_md = [img.copy() for img in p.init_images]
+        p.width_original_md, p.height_original_md = p.width, p.height
+
         is_img2img = hasattr(p, "init_images") and len(getattr(p, "init_images", []) or []) > 0
+        upscaled = False
         if is_img2img:
-            idx = [x.name for x in shared.sd_upscalers].index(upscaler_name) if shared.sd_upscalers else -1
-            if idx >= 0 and shared.sd_upscalers[idx].name != "None" and scale_factor > 1.0:
-                upscaler = shared.sd_upscalers[idx]
+            names = [x.name for x in shared.sd_upscalers]
+            upscaler = shared.sd_upscalers[names.index(upscaler_name)] if upscaler_name in names else None
+            image = p.init_images[0]
+            try:
+                from modules import images
+                image = images.flatten(image, opts.img2img_background_color)
+            except Exception:   # bare test host: nothing to flatten
+                pass
+            if upscaler is not None and upscaler.name != "None":
                 print(f"[Tiled Diffusion] upscaling image with {upscaler.name}...")
-                p.init_images[:] = [upscaler.scaler.upscale(img, scale_factor, upscaler.data_path) for img in p.init_images]
+                image = upscaler.scaler.upscale(image, scale_factor, upscaler.data_path)
                 p.extra_generation_params["Tiled Diffusion upscaler"] = upscaler.name
                 p.extra_generation_params["Tiled Diffusion scale factor"] = scale_factor
+                for i in range(len(p.init_images)):       # folder-based batches hold several entries: all become the upscaled image
+                    p.init_images[i] = image
+                upscaled = True
             if keep_input_size:
-                p.width_original_md, p.height_original_md = p.width, p.height
-                p.width, p.height = p.init_images[0].width, p.init_images[0].height
+                p.width, p.height = image.width, image.height
+            elif upscaled:
+                p.width, p.height = int(scale_factor * p.width_original_md), int(scale_factor * p.height_original_md)
         elif overwrite_size:
-            p.width_original_md, p.height_original_md = p.width, p.height
             p.width, p.height = image_width, image_height
 
-        if noise_inverse:
-            print("[Tiled Diffusion] Noise Inversion is not available in the mdtile engine build; ignored.")
         bbox_settings = build_bbox_settings(bbox_control_states) if enable_bbox_control else {}
-        if not splitable(p.width, p.height, tile_width, tile_height, overlap) and not bbox_settings:
-            print("[Tiled Diffusion] ignored: the image fits one tile and no region is enabled.")
+        if not (splitable(p.width, p.height, tile_width, tile_height, overlap) or enable_bbox_control or (is_img2img and noise_inverse)):
+            print("[Tiled Diffusion] ignored: the image fits one tile and there is nothing else to do.")
             return
 
         info = {"Method": method, "Tile tile width": tile_width, "Tile tile height": tile_height,
                 "Tile Overlap": overlap, "Tile batch size": tile_batch_size}
+        if is_img2img:
+            if upscaled:
+                info["Upscaler"], info["Upscale factor"] = upscaler.name, scale_factor
+            if keep_input_size:
+                info["Keep input size"] = keep_input_size
+            if noise_inverse:
+                info.update({"NoiseInv": noise_inverse, "NoiseInv Steps": noise_inverse_steps, "NoiseInv Retouch": noise_inverse_retouch,
+                             "NoiseInv Renoise strength": noise_inverse_renoise_strength, "NoiseInv Kernel size": noise_inverse_renoise_kernel})
         if bbox_settings:
             info["Region control"] = {f"Region {i + 1}": s._asdict() for i, s in bbox_settings.items()}
         if not hasattr(p, "extra_generation_params") or p.extra_generation_params is None:
             p.extra_generation_params = {}
         p.extra_generation_params["Tiled Diffusion"] = info
 
+        # other extensions whose tensors have to follow the tiles (upstream :344-361)
+        self.controlnet_script = self.stablesr_script = None
+        runner = getattr(p, "scripts", None)
+        if runner is not None:
+            try:
+                import scripts.cldm  # noqa: F401   (only tells whether sd-webui-controlnet is installed)
+                for sc in list(getattr(runner, "scripts", [])) + list(getattr(runner, "alwayson_scripts", [])):
+                    if hasattr(sc, "latest_network") and sc.title().lower() == "controlnet":
+                        self.controlnet_script = sc
+                        print("[Tiled Diffusion] ControlNet found, support is enabled.")
+                        break
+            except ImportError:
+                pass
+            for sc in getattr(runner, "scripts", []):
+                if hasattr(sc, "stablesr_model") and sc.title().lower() == "stablesr" and sc.stablesr_model is not None:
+                    self.stablesr_script = sc
+                    print("[Tiled Diffusion] StableSR found, support is enabled.")
+                    break
+
         Script.create_sampler_original_md = sd_samplers.create_sampler
         sd_samplers.create_sampler = lambda name, model: self.create_sampler_hijack(
             name, model, p, Method(method), tile_width, tile_height, overlap, tile_batch_size,
-            enable_bbox_control, draw_background, causal_layers, bbox_settings)
+            noise_inverse, noise_inverse_steps, noise_inverse_retouch, noise_inverse_renoise_strength, noise_inverse_renoise_kernel,
+            control_tensor_cpu, enable_bbox_control, draw_background, causal_layers, bbox_settings)
 
         if enable_bbox_control:
             # every region gets its own seeded initial noise (upstream :376-383)
@@ -172,36 +214,68 @@ class Script(scripts.Script):
         if not enabled:
             return
         self.reset()
+        if hasattr(p, "init_images") and hasattr(p, "init_images_original_md"):
+            p.init_images.clear()       # keep the list OBJECT: XYZ-plot works on shallow copies of p
+            p.init_images.extend(p.init_images_original_md)
+            del p.init_images_original_md
         if hasattr(p, "width_original_md"):
             p.width, p.height = p.width_original_md, p.height_original_md
             del p.width_original_md, p.height_original_md
+        if hasattr(p, "noise_inverse_latent"):
+            del p.noise_inverse_latent
 
     # ---- hijack ---------------------------------------------------------------------------------------------------
     def create_sampler_hijack(self, name: str, model, p, method: Method, tile_width: int, tile_height: int, overlap: int,
-                              tile_batch_size: int, enable_bbox_control: bool, draw_background: bool,
-                              causal_layers: bool, bbox_settings):
+                              tile_batch_size: int, noise_inverse: bool, noise_inverse_steps: int, noise_inverse_retouch: float,
+                              noise_inverse_renoise_strength: float, noise_inverse_renoise_kernel: int, control_tensor_cpu: bool,
+                              enable_bbox_control: bool, draw_background: bool, causal_layers: bool, bbox_settings):
         if self.delegate is not None and self.delegate.sampler_name == name:
-            # second call within one job (e.g. hires fix): keep the delegate, just re-arm Mixture of Diffusers
+            # second call within one job (e.g. hires fix, ControlNet batches): keep the delegate, refresh what follows the tiles
+            if self.controlnet_script:
+                self.delegate.prepare_controlnet_tensors(refresh=True)
             if isinstance(self.delegate, MixtureOfDiffusers):
                 self.delegate.hook()
             return self.delegate.sampler_raw
         self.reset(keep_sampler_hijack=True)
 
+        flag_noise_inverse = hasattr(p, "init_images") and len(p.init_images) > 0 and noise_inverse
+        if flag_noise_inverse:
+            print('[Tiled Diffusion] Noise Inversion only supports the "Euler" sampler: switching to it.')
+            name = "Euler"
+            p.sampler_name = "Euler"
         sampler = Script.create_sampler_original_md(name, model)
         cls = MultiDiffusion if method == Method.MULTI_DIFF else MixtureOfDiffusers
         delegate = cls(p, sampler)
+        if flag_noise_inverse:
+            delegate.init_noise_inverse(noise_inverse_steps, noise_inverse_retouch, self.noise_inverse_get_cache,
+                                        lambda x0, xt, prompts: self.noise_inverse_set_cache(p, x0, xt, prompts, noise_inverse_steps, noise_inverse_retouch),
+                                        noise_inverse_renoise_strength, noise_inverse_renoise_kernel)
         if not enable_bbox_control or draw_background:
             delegate.init_grid_bbox(tile_width, tile_height, overlap, tile_batch_size)
         if enable_bbox_control and bbox_settings:
             delegate.init_custom_bbox(bbox_settings, draw_background, causal_layers)
+        if self.controlnet_script:
+            delegate.init_controlnet(self.controlnet_script, control_tensor_cpu)
+        if self.stablesr_script:
+            delegate.init_stablesr(self.stablesr_script)
         delegate.init_done()
         delegate.hook()
         self.delegate = delegate
 
+        exts = [n for n, on in (("NoiseInv", flag_noise_inverse), ("RegionCtrl", enable_bbox_control), ("ControlNet", bool(self.controlnet_script)),
+                                ("StableSR", bool(self.stablesr_script))) if on]
         print(f"[Tiled Diffusion] {method.value} hooked into {name!r} sampler; tile {tile_width}x{tile_height}, "
               f"overlap {overlap}, batch {tile_batch_size}, {delegate.num_tiles or 0} tiles in "
-              f"{delegate.num_batches or 0} batches" + (f", {len(delegate.custom_bboxes)} regions" if delegate.custom_bboxes else ""))
+              f"{delegate.num_batches or 0} batches" + (f", {len(delegate.custom_bboxes)} regions" if delegate.custom_bboxes else "")
+              + (f"; ext: {', '.join(exts)}" if exts else ""))
         return delegate.sampler_raw
+
+    def noise_inverse_set_cache(self, p, x0, xt, prompts, steps: int, retouch: float):
+        from tile_utils.utils import NoiseInverseCache
+        self.noise_inverse_cache = NoiseInverseCache(p.sd_model.sd_model_hash, x0, xt, steps, retouch, prompts)
+
+    def noise_inverse_get_cache(self):
+        return self.noise_inverse_cache
 
     def create_random_tensors_hijack(self, bbox_settings, region_info, shape, seeds, subseeds=None, subseed_strength=0.0,
                                      seed_resize_from_h=0, seed_resize_from_w=0, p=None):

@@ -215,7 +215,12 @@ class VAEHook:
         self.pad = 11 if is_decoder else 32
         self._program: Optional[List[Step]] = None
         self.last_seconds = None
-        self.shard = (0, 1)   # (rank, world): multi-GPU runs decode tiles rank, rank+world, ... (mdtile/sharding.py)
+        self.shard = (0, 1)   # (rank, world): process-per-GPU runs decode tiles rank, rank+world, ... (mdtile/sharding.py)
+        # single-process multi-device decode (what a webui process can use): CUDA device indices, e.g. [0, 1, 2, 3]; the tiles are
+        # dealt round-robin to the devices, each with its own copy of the packed weights; fast mode only (no collective needed:
+        # the frozen statistics are computed once and copied).  A device may be listed twice (functional runs on one GPU).
+        self.devices: Optional[List[int]] = None
+        self._dev_programs = {}
 
     def __call__(self, x):
         original_device = next(self.net.parameters()).device
@@ -371,9 +376,12 @@ class VAEHook:
             if len(frozen) == n_norm:
                 break
             self._apply_norm(steps, st, var, mean)
-            if torch.isnan(st.x).any().item():
-                print("Nan detected in fast mode estimation. Fast mode disabled.")
-                return None
+        # upstream tests the activation for NaN after every norm (:487-490) and falls back to slow mode; a NaN anywhere upstream of a
+        # norm poisons that norm's statistics, so ONE test of the frozen (var, mean) rows at the end sees the same events without a
+        # host sync per norm
+        if frozen and bool(torch.isnan(torch.stack([v.sum() + m.sum() for v, m in frozen])).any().item()):
+            print("Nan detected in fast mode estimation. Fast mode disabled.")
+            return None
         return frozen
 
     def _pooled_across_ranks(self, gp: "GroupNormParam", steps, dev):
@@ -395,6 +403,71 @@ class VAEHook:
             BG = int(shape.item())
             sm, sv, sp = torch.zeros(BG, device=dev), torch.zeros(BG, device=dev), torch.zeros(1, device=dev)
         return sharding.allreduce_stats(sm, sv, sp)
+
+    # ---- single-process multi-device sweep ---------------------------------------------------------------------------------
+    def _program_on(self, index: int) -> List[Step]:
+        """The task queue with its weights packed on CUDA device `index` (built once per device)."""
+        import copy
+        if index not in self._dev_programs:
+            d = torch.device("cuda", index)
+            src = next(self.net.parameters()).device
+            net = self.net if src == d else copy.deepcopy(self.net).to(d)
+            with torch.cuda.device(d):
+                self._dev_programs[index] = build_task_queue(net, self.is_decoder, self._pack, self.engine)
+        return self._dev_programs[index]
+
+    def _multi_device_sweep(self, z: Tensor, steps0: List[Step], frozen, in_bboxes, out_bboxes, dtype, t0) -> Tensor:
+        """Fast mode on several devices of ONE process: tile i runs on devices[i % n] (own stream, own packed weights, the frozen
+        statistics copied over); launches are asynchronous, so one Python thread keeps all devices busy.  The output tiles are
+        disjoint (out_bboxes never overlap): each device crops into its own canvas and its rectangles are copied to the first
+        device at the end (peer copies over xGMI)."""
+        E = self.engine
+        N, _, height, width = z.shape
+        devs = [torch.device("cuda", i) for i in self.devices]
+        norm_idx = [i for i, s in enumerate(steps0) if s.kind == "norm"]
+        norm_ord = {i: k for k, i in enumerate(norm_idx)}
+        per = []
+        for d in devs:
+            with torch.cuda.device(d):
+                steps = self._program_on(d.index)
+                fz = [(v.to(d), m.to(d)) for (v, m) in frozen]
+                coefs = [E.gn_coeffs(m, v, steps[i].norm[0], steps[i].norm[1], steps[i].channels, 32, 1e-6) for i, (v, m) in zip(norm_idx, fz)]
+                per.append(dict(steps=steps, frozen=fz, coefs=coefs, z=z.to(d), result=None, flags=[], mine=[]))
+        for i in range(len(in_bboxes)):
+            if state.interrupted:
+                break
+            k = i % len(devs)
+            L, d = per[k], devs[k]
+            with torch.cuda.device(d):
+                b = in_bboxes[i]
+                x = E.gather_rect(L["z"], b[0], b[2], b[1] - b[0], b[3] - b[2])
+                x = self._run_tile_rec(L["steps"], x, L["frozen"], L["coefs"], norm_ord)
+                if L["result"] is None:
+                    oh, ow = (height * 8, width * 8) if self.is_decoder else (height // 8, width // 8)
+                    L["result"] = torch.zeros((N, x.shape[1], oh, ow), device=d, dtype=torch.float32)
+                L["flags"].append(torch.isnan(x).all())
+                E.crop_store(x, in_bboxes[i], out_bboxes[i], L["result"], self.is_decoder)
+                L["mine"].append(i)
+        if state.interrupted or per[0]["result"] is None:
+            from modules.sd_vae_approx import cheap_approximation
+            return torch.cat([torch.nn.functional.interpolate(cheap_approximation(x).unsqueeze(0), scale_factor=8, mode="nearest-exact")
+                              for x in z], dim=0).to(devs[0], dtype=dtype)
+        out = per[0]["result"]
+        bad = False
+        for k, L in enumerate(per):
+            torch.cuda.current_stream(devs[k]).synchronize()
+            bad = bad or (L["flags"] and bool(torch.stack(L["flags"]).any().item()))
+            if k == 0 or L["result"] is None:
+                continue
+            for i in L["mine"]:
+                x1, x2, y1, y2 = out_bboxes[i]
+                out[:, :, y1:y2, x1:x2].copy_(L["result"][:, :, y1:y2, x1:x2])
+        if bad:
+            devices.test_for_nans(torch.full((1,), float("nan")), "vae")
+        self.last_seconds = time() - t0
+        torch.cuda.synchronize(devs[0])
+        print(f"[Tiled VAE]: Done in {time() - t0:.3f}s on {len(devs)} devices")
+        return out.to(dtype)
 
     @torch.no_grad()
     def vae_tile_forward(self, z: Tensor) -> Tensor:
@@ -429,19 +502,23 @@ class VAEHook:
         result = None
         interrupted = False
 
+        nan_flags = []
+
         def finish(i: int):
             nonlocal result
             x = tiles[i].x
             if result is None:
                 oh, ow = (height * 8, width * 8) if self.is_decoder else (height // 8, width // 8)
                 result = torch.zeros((N, x.shape[1], oh, ow), device=dev, dtype=torch.float32)
-            devices.test_for_nans(x, "vae")
+            nan_flags.append(torch.isnan(x).all())       # upstream tests every tile (:626); here ONE host read per decode, below
             E.crop_store(x, in_bboxes[i], out_bboxes[i], result, self.is_decoder)
             tiles[i] = None
 
         n_norm_total = sum(1 for s in steps if s.kind == "norm")
         if frozen is not None and len(frozen) == n_norm_total:
             # every norm is already resolved: each tile runs start to finish on its own (upstream: one sweep)
+            if self.devices and len(self.devices) > 1 and dev.type == "cuda":
+                return self._multi_device_sweep(z, steps, frozen, in_bboxes, out_bboxes, dtype, t0)
             use_rec = REC_PATH and hasattr(E, "rec_from_f32")
             if use_rec:
                 norm_ord = {i: k for k, i in enumerate(i for i, s in enumerate(steps) if s.kind == "norm")}
@@ -497,8 +574,14 @@ class VAEHook:
                     self._apply_norm(steps, tiles[i], *pooled)
                 forward = not forward
 
+        if nan_flags and bool(torch.stack(nan_flags).any().item()):
+            devices.test_for_nans(torch.full((1,), float("nan")), "vae")     # raises the host's NansException (or not: --disable-nan-check)
         self.last_seconds = time() - t0
-        if interrupted or result is None:
+        if interrupted and result is not None:
+            return result.to(dtype)          # upstream hands back what is finished (:644-647)
+        if result is None:
+            if not self.is_decoder:
+                raise RuntimeError("[Tiled VAE]: interrupted before any encoder tile finished")
             from modules.sd_vae_approx import cheap_approximation
             approx = torch.cat([torch.nn.functional.interpolate(cheap_approximation(x).unsqueeze(0), scale_factor=8,
                                                                 mode="nearest-exact") for x in z], dim=0)

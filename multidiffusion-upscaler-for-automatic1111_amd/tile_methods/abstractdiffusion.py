@@ -7,12 +7,14 @@ land on the same surface.  Everything numerical is delegated to the mdtile engin
     custom bbox rects      upstream :194-215            -> host ints here, maps in the subclasses
     reset_buffer           upstream :97-102             -> nothing to clear: the blend is gather-formulated
 
-Out of scope here (host-coupled glue): ControlNet / StableSR tensor slicing and Noise Inversion;
-their entry points exist as inert hooks so a caller that pokes them does not crash.
+    ControlNet / StableSR  upstream :475-588            -> mdtile_gather_rects (slice + cat + repeat in one launch, no tile caches)
+    Noise Inversion        upstream :591-747            -> host Euler inversion loop around get_noise (= the blend) and
+                                                           mdtile_noise_inverse_blend for the renoise composite (:651-676)
 """
 from __future__ import annotations
 
 import math
+from types import MethodType
 from typing import Dict, List, Optional
 
 import torch
@@ -23,7 +25,7 @@ from modules.shared import state
 from modules.processing import opt_f
 
 import mdtile
-from tile_utils.utils import BBox, BBoxSettings, BlendMode, Condition, CustomBBox, Prompt
+from tile_utils.utils import BBox, BBoxSettings, BlendMode, Condition, CustomBBox, NoiseInverseCache, Prompt, get_retouch_mask
 
 try:  # isinstance targets; absent in a bare test host
     from modules.sd_samplers_kdiffusion import KDiffusionSampler
@@ -75,10 +77,16 @@ class AbstractDiffusion:
         self.draw_background = True
         self.causal_layers = None
 
-        # inert extension points (ControlNet / StableSR / noise inversion are not part of this engine)
+        # optional extensions, armed by the init_* calls of the Script
         self.noise_inverse_enabled = False
+        self.sample_img2img_original = None
         self.enable_controlnet = False
+        self.controlnet_script = None
+        self.control_params = None
+        self.org_control_tensor_batch = None
         self.enable_stablesr = False
+        self.stablesr_script = None
+        self.stablesr_tensor = None
 
     # ------------------------------------------------------------------------------------------------ host plumbing
     @property
@@ -237,42 +245,300 @@ class AbstractDiffusion:
         """Per region: feather mask (foreground) or the method's background weight (None = 1.0)."""
         return [b.feather_mask if b.blend_mode == BlendMode.FOREGROUND else None for b in self.custom_bboxes]
 
-    # region-prompt forwards: uniform-prompt reconstruction through the host's prompt parser
+    # ---- region-prompt forwards (upstream :232-451) --------------------------------------------------------------------
+    def reconstruct_custom_cond(self, org_cond, custom_cond, custom_uncond, bbox: CustomBBox):
+        """(region prompt tensor, region negative-prompt tensor, image conditioning cut to the region) at the sampler's step."""
+        icond = self.slice_icond(self.get_icond(org_cond), bbox) if isinstance(org_cond, dict) else None
+        step = self.sampler.model_wrap_cfg.step
+        return Condition.reconstruct_cond(custom_cond, step), Condition.reconstruct_uncond(custom_uncond, step), icond
+
+    def _region_forward(self, forward_func, x, sigma, org_cond, tcond, icond, bbox_id, n_control):
+        self.set_custom_controlnet_tensors(bbox_id, n_control)
+        self.set_custom_stablesr_tensors(bbox_id)
+        cond = self.make_cond_dict(org_cond, tcond, icond, self.get_vcond(org_cond)) if isinstance(org_cond, dict) else tcond
+        return forward_func(x, sigma, cond=cond)
+
+    def _split_forward(self, forward_func, x_tile, sigma_in, org_cond, first, second, icond, bbox_id, tail_repeats_second=False):
+        """Two model calls for prompt tensors of different token length (they cannot be concatenated); rows beyond the two chunks
+        (edit models: a second uncond copy) reuse the second result."""
+        n1, n2 = first.shape[0], second.shape[0]
+        x_out = torch.zeros_like(x_tile)
+        ic1 = icond[:n1] if icond is not None and icond.shape[0] >= n1 + n2 else icond
+        ic2 = icond[n1:n1 + n2] if icond is not None and icond.shape[0] >= n1 + n2 else icond
+        x_out[:n1] = self._region_forward(forward_func, x_tile[:n1], sigma_in[:n1], org_cond, first, ic1, bbox_id, n1)
+        out2 = self._region_forward(forward_func, x_tile[n1:n1 + n2], sigma_in[n1:n1 + n2], org_cond, second, ic2, bbox_id, n2)
+        x_out[n1:n1 + n2] = out2
+        if tail_repeats_second and x_tile.shape[0] > n1 + n2:
+            x_out[n1 + n2:] = out2
+        return x_out
+
     def kdiff_custom_forward(self, x_tile: Tensor, sigma_in: Tensor, original_cond, bbox_id: int, bbox: CustomBBox,
                              forward_func):
-        """One region evaluated with its own prompt (k-diffusion samplers).  Batched cond+uncond, no 'AND' support:
-        the elaborate per-host-version branches of upstream :246-427 are host glue, not part of the engine."""
+        """One region evaluated with its own prompt under a k-diffusion sampler.  The host's CFG denoiser feeds either the whole
+        [cond, uncond(, uncond)] batch at once or slices of it (batch_cond_uncond off, --lowvram / --medvram, prompts of different
+        token length); the region's tensors are sliced the same way (upstream :246-427)."""
         step = self.sampler.model_wrap_cfg.step
-        tcond = Condition.reconstruct_cond(bbox.cond, step)
-        uncond = Condition.reconstruct_uncond(bbox.uncond, step)
-        n_cond = x_tile.shape[0] - uncond.shape[0]
-        tcond = tcond[:n_cond] if tcond.shape[0] >= n_cond else tcond.expand(n_cond, *tcond.shape[1:])
-        icond = self.slice_icond(self.get_icond(original_cond), bbox) if isinstance(original_cond, dict) else None
-        cond_in = torch.cat([tcond, uncond], dim=0)
-        if isinstance(original_cond, dict):
-            cond_out = self.make_cond_dict(original_cond, cond_in, icond, self.get_vcond(original_cond))
-        else:
-            cond_out = cond_in
-        return forward_func(x_tile, sigma_in, cond=cond_out)
+        if self.kdiff_step != step:               # first region call of a sampler step: forget the per-step progress
+            self.kdiff_step = step
+            self.kdiff_step_bbox = [-1] * len(self.custom_bboxes)
+            self.tensor, self.uncond, self.image_cond_in = {}, {}, {}
+            # the GLOBAL prompts only tell how the host batches this step
+            self.real_tensor = Condition.reconstruct_cond(self.cond_basis, step)
+            self.real_uncond = Condition.reconstruct_uncond(self.uncond_basis, step)
+            self.a = [0] * len(self.custom_bboxes)
+        same_len_global = self.real_tensor.shape[1] == self.real_uncond.shape[1]
+        edit = bool(getattr(self, "is_edit_model", False))
+
+        if self.kdiff_step_bbox[bbox_id] != step:
+            self.kdiff_step_bbox[bbox_id] = step
+            tensor, uncond, icond = self.reconstruct_custom_cond(original_cond, bbox.cond, bbox.uncond, bbox)
+            if same_len_global and shared.batch_cond_uncond:
+                # the whole batch is in x_tile
+                if tensor.shape[1] == uncond.shape[1]:
+                    cond = torch.cat([tensor, uncond, uncond] if edit else [tensor, uncond])
+                    return self._region_forward(forward_func, x_tile, sigma_in, original_cond, cond, icond, bbox_id, x_tile.shape[0])
+                return self._split_forward(forward_func, x_tile, sigma_in, original_cond, tensor, uncond, icond, bbox_id, tail_repeats_second=edit)
+            self.tensor[bbox_id], self.uncond[bbox_id], self.image_cond_in[bbox_id] = tensor, uncond, icond
+
+        # partial batches: rows [a, b) of the virtual [tensor, uncond(, uncond)] stack
+        tensor, uncond, icond = self.tensor[bbox_id], self.uncond[bbox_id], self.image_cond_in[bbox_id]
+        a = self.a[bbox_id]
+        b = a + x_tile.shape[0]
+        self.a[bbox_id] = b
+        nt, nu = tensor.shape[0], uncond.shape[0]
+        if same_len_global:
+            # segments of the stack covered by [a, b): (source, lo, hi)
+            stack = [(tensor, 0, nt), (uncond, nt, nt + nu)] + ([(uncond, nt + nu, nt + 2 * nu)] if edit else [])
+            parts = [src[max(a, lo) - lo:min(b, hi) - lo] for src, lo, hi in stack if max(a, lo) < min(b, hi)]
+            if len(parts) == 1 or all(p_.shape[1] == parts[0].shape[1] for p_ in parts):
+                cond = parts[0] if len(parts) == 1 else torch.cat(parts)
+                return self._region_forward(forward_func, x_tile, sigma_in, original_cond, cond, icond, bbox_id, x_tile.shape[0])
+            first, second = parts[0], torch.cat(parts[1:])
+            return self._split_forward(forward_func, x_tile, sigma_in, original_cond, first, second, icond, bbox_id)
+        # global prompts of different length: the host runs cond and uncond in separate calls, so do the regions
+        if a < nt:
+            cond = tensor[a:b] if not edit else torch.cat([tensor[a:b], uncond])
+            return self._region_forward(forward_func, x_tile, sigma_in, original_cond, cond, icond, bbox_id, x_tile.shape[0])
+        return self._region_forward(forward_func, x_tile, sigma_in, original_cond, uncond, icond, bbox_id, uncond.shape[0])
 
     def ddim_custom_forward(self, x: Tensor, cond_in, bbox: CustomBBox, ts: Tensor, forward_func, *args, **kwargs):
-        step = getattr(self.sampler, "step", state.sampling_step)
-        tcond = Condition.reconstruct_cond(bbox.cond, step)
-        uncond = Condition.reconstruct_uncond(bbox.uncond, step)
-        icond = self.slice_icond(self.get_icond(cond_in), bbox) if isinstance(cond_in, dict) else None
-        if isinstance(cond_in, dict):
-            cond = self.make_cond_dict(cond_in, tcond, icond)
-            uc = self.make_cond_dict(cond_in, uncond, icond)
+        """One region under a CompVis (DDIM / PLMS) sampler: cond and uncond travel as two arguments and are concatenated later,
+        so the negative prompt is padded with its last token vector / truncated to the prompt's length (upstream :429-451)."""
+        tcond, uncond, icond = self.reconstruct_custom_cond(cond_in, bbox.cond, bbox.uncond, bbox)
+        if uncond.shape[1] < tcond.shape[1]:
+            uncond = torch.hstack([uncond, uncond[:, -1:].repeat([1, tcond.shape[1] - uncond.shape[1], 1])])
+        elif uncond.shape[1] > tcond.shape[1]:
+            uncond = uncond[:, :tcond.shape[1]]
+        if icond is not None:
+            cond, uc = self.make_cond_dict(cond_in, tcond, icond), self.make_cond_dict(cond_in, uncond, icond)
         else:
             cond, uc = tcond, uncond
         return forward_func(x, cond, ts, unconditional_conditioning=uc, *args, **kwargs)
 
-    # inert hooks --------------------------------------------------------------------------------------------------------
-    def init_controlnet(self, *a, **k): self.enable_controlnet = False
-    def init_stablesr(self, *a, **k): self.enable_stablesr = False
-    def init_noise_inverse(self, *a, **k): self.noise_inverse_enabled = False
-    def reset_controlnet_tensors(self): pass
-    def switch_controlnet_tensors(self, *a, **k): pass
-    def set_custom_controlnet_tensors(self, *a, **k): pass
-    def switch_stablesr_tensors(self, *a, **k): pass
-    def set_custom_stablesr_tensors(self, *a, **k): pass
+    # ---- ControlNet (upstream :454-544) ---------------------------------------------------------------------------------
+    # Upstream crops every hint into per-batch tile stacks at init (optionally parked on the CPU) and re-assembles / repeats /
+    # uploads them at every model call.  Here the full hints stay where they are and one mdtile_gather_rects launch per hint
+    # produces the sliced + repeated tensor when a batch is switched in -- nothing is cached.
+    def init_controlnet(self, controlnet_script, control_tensor_cpu: bool):
+        self.enable_controlnet = True
+        self.controlnet_script = controlnet_script
+        self.control_tensor_cpu = control_tensor_cpu      # accepted for the UI's sake: there are no tile caches to park
+        self.control_params = None
+        self.org_control_tensor_batch = None
+        self.prepare_controlnet_tensors()
+
+    def reset_controlnet_tensors(self):
+        if not self.enable_controlnet or self.org_control_tensor_batch is None:
+            return
+        for param, hint in zip(self.control_params, self.org_control_tensor_batch):
+            param.hint_cond = hint
+
+    def prepare_controlnet_tensors(self, refresh: bool = False):
+        """Remember the network's control params and their ORIGINAL hints (full canvas, opt_f x the latent grid)."""
+        if not refresh and self.control_params is not None:
+            return
+        if not self.enable_controlnet or self.controlnet_script is None:
+            return
+        net = getattr(self.controlnet_script, "latest_network", None)
+        if net is None or not hasattr(net, "control_params"):
+            return
+        self.control_params = net.control_params
+        hints = []
+        for param in self.control_params:
+            h = param.hint_cond
+            hints.append(h.unsqueeze(0) if h.dim() == 3 else h)
+        self.org_control_tensor_batch = hints
+
+    def _hint_on_device(self, hint: Tensor) -> Tensor:
+        return hint if hint.device.type == "cuda" else hint.to(devices.device)
+
+    def switch_controlnet_tensors(self, batch_id: int, x_batch_size: int, tile_batch_size: int, is_denoise: bool = False):
+        if not self.enable_controlnet or not self.org_control_tensor_batch:
+            return
+        bboxes = self.batched_bboxes[batch_id]
+        rects = [(b.x * opt_f, b.y * opt_f) for b in bboxes]
+        w, h = bboxes[0].w * opt_f, bboxes[0].h * opt_f
+        for param, hint in zip(self.control_params, self.org_control_tensor_batch):
+            hint = self._hint_on_device(hint).contiguous()
+            if self.is_kdiff:      # every tile's x_batch_size copies are consecutive (tile-major model batch)
+                param.hint_cond = mdtile.gather_rects(hint[:1], rects[:tile_batch_size], w, h, repeat=x_batch_size, tile_major=True)
+            else:                  # DDIM: the tile stack as a whole, repeated for cond + uncond (once when only denoising)
+                param.hint_cond = mdtile.gather_rects(hint, rects, w, h, repeat=x_batch_size if is_denoise else x_batch_size * 2, tile_major=False)
+
+    def set_custom_controlnet_tensors(self, bbox_id: int, repeat_size: int):
+        if not self.enable_controlnet or not self.org_control_tensor_batch or not self.custom_bboxes:
+            return
+        bbox = self.custom_bboxes[bbox_id]
+        for param, hint in zip(self.control_params, self.org_control_tensor_batch):
+            hint = self._hint_on_device(hint).contiguous()
+            param.hint_cond = mdtile.gather_rects(hint, [(bbox.x * opt_f, bbox.y * opt_f)], bbox.w * opt_f, bbox.h * opt_f,
+                                                  repeat=repeat_size, tile_major=False)
+
+    # ---- StableSR (upstream :547-588) --------------------------------------------------------------------------------------
+    def init_stablesr(self, stablesr_script):
+        if stablesr_script.stablesr_model is None:
+            return
+        self.stablesr_script = stablesr_script
+
+        def set_image_hook(latent_image: Tensor):
+            self.enable_stablesr = True
+            self.stablesr_tensor = latent_image
+
+        stablesr_script.stablesr_model.set_image_hooks["TiledDiffusion"] = set_image_hook
+
+    def _stablesr_live(self) -> bool:
+        return self.enable_stablesr and self.stablesr_script is not None and self.stablesr_script.stablesr_model is not None \
+            and self.stablesr_tensor is not None
+
+    def reset_stablesr_tensors(self):
+        if self._stablesr_live():
+            self.stablesr_script.stablesr_model.latent_image = self.stablesr_tensor
+
+    def switch_stablesr_tensors(self, batch_id: int):
+        if not self._stablesr_live():
+            return
+        bboxes = self.batched_bboxes[batch_id]
+        t = self.stablesr_tensor.contiguous()
+        self.stablesr_script.stablesr_model.latent_image = mdtile.gather_rects(t, [(b.x, b.y) for b in bboxes], bboxes[0].w, bboxes[0].h)
+
+    def set_custom_stablesr_tensors(self, bbox_id: int):
+        if not self._stablesr_live() or not self.custom_bboxes:
+            return
+        bbox = self.custom_bboxes[bbox_id]
+        self.stablesr_script.stablesr_model.latent_image = mdtile.gather_rect(self.stablesr_tensor.contiguous(), bbox.x, bbox.y, bbox.w, bbox.h)
+
+    # ---- Noise Inversion (upstream :591-747) -----------------------------------------------------------------------------
+    def init_noise_inverse(self, steps: int, retouch: float, get_cache_callback, set_cache_callback, renoise_strength: float,
+                           renoise_kernel: int):
+        self.noise_inverse_enabled = True
+        self.noise_inverse_steps = steps
+        self.noise_inverse_retouch = float(retouch)
+        self.noise_inverse_renoise_strength = float(renoise_strength)
+        self.noise_inverse_renoise_kernel = int(renoise_kernel)
+        if self.sample_img2img_original is None:
+            self.sample_img2img_original = self.sampler_raw.sample_img2img
+        self.sampler_raw.sample_img2img = MethodType(self.sample_img2img, self.sampler_raw)
+        self.noise_inverse_set_cache = set_cache_callback
+        self.noise_inverse_get_cache = get_cache_callback
+
+    def renoise_mask(self, p, size) -> Optional[Tensor]:
+        """[H, W] weight of fresh noise: where the guided filter says the input image has detail, scaled by the renoise strength
+        (upstream :607-616)."""
+        if self.noise_inverse_renoise_strength <= 0:
+            return None
+        import numpy as np
+        import torch.nn.functional as F
+        gray = np.asarray(p.init_images[0].convert("L"))
+        m = torch.from_numpy(get_retouch_mask(gray, self.noise_inverse_renoise_kernel)).to(devices.device)
+        m = 1 - F.interpolate(m.unsqueeze(0).unsqueeze(0), size=size, mode="bilinear").squeeze(0).squeeze(0)
+        m *= self.noise_inverse_renoise_strength
+        return torch.clamp(m, 0, 1)
+
+    def _cached_inversion(self, p, prompts) -> Optional[Tensor]:
+        c = self.noise_inverse_get_cache()
+        if c is None:
+            return None
+        same = (c.model_hash == p.sd_model.sd_model_hash and c.noise_inversion_steps == self.noise_inverse_steps
+                and len(c.prompts) == len(prompts) and all(a == b for a, b in zip(c.prompts, prompts))
+                and abs(c.retouch - self.noise_inverse_retouch) < 0.01 and c.x0.shape == p.init_latent.shape
+                and torch.abs(c.x0.to(p.init_latent.device) - p.init_latent).sum() < 100)
+        return c.xt if same else None
+
+    def sample_img2img(self, sampler, p, x: Tensor, noise: Tensor, conditioning, unconditional_conditioning, steps=None,
+                       image_conditioning=None):
+        """Replacement of the sampler's sample_img2img: the img2img start noise is the noise that INVERTS the init image
+        (tiled Euler inversion through get_noise), mixed with fresh noise where the image has detail (upstream :606-681)."""
+        from modules import sd_samplers_common
+        renoise_mask = self.renoise_mask(p, tuple(noise.shape[-2:]))
+        prompts = p.all_prompts[:p.batch_size]
+        latent = self._cached_inversion(p, prompts)
+        if latent is not None:
+            print("[Tiled Diffusion] checkpoint, image, prompts, inversion steps and retouch are unchanged: "
+                  "Noise Inversion reuses the latent of the previous run.")
+            latent = latent.to(noise.device)
+        else:
+            shared.state.job_count += 1
+            latent = self.find_noise_for_image_sigma_adjustment(sampler.model_wrap, self.noise_inverse_steps, prompts)
+            shared.state.nextjob()
+            self.noise_inverse_set_cache(p.init_latent.clone().cpu(), latent.clone().cpu(), prompts)
+        adjusted_steps, _ = sd_samplers_common.setup_img2img_steps(p, steps)
+        sigmas = sampler.get_sigmas(p, adjusted_steps)
+        inverse_noise = latent - (p.init_latent / sigmas[0])
+        if renoise_mask is not None:
+            # :655-676 -- one engine launch.  With the grid disabled the job's noise is first re-weighted by the regions.
+            regions = []
+            if not self.enable_grid_bbox:
+                for b in self.custom_bboxes:
+                    fg = b.blend_mode == BlendMode.FOREGROUND
+                    regions.append((b.x, b.y, b.w, b.h, mdtile.REGION_FG if fg else mdtile.REGION_BG,
+                                    b.feather_mask.to(device=noise.device, dtype=torch.float32).contiguous() if fg else None))
+            combined = mdtile.noise_inverse_blend(noise.float().contiguous(), inverse_noise.float().contiguous(),
+                                                  renoise_mask.float().contiguous(), regions).to(noise.dtype)
+        else:
+            combined = inverse_noise
+        return self.sample_img2img_original(p, x, combined, conditioning, unconditional_conditioning, steps, image_conditioning)
+
+    @torch.no_grad()
+    def find_noise_for_image_sigma_adjustment(self, dnw, steps: int, prompts: List[str]) -> Tensor:
+        """Euler inversion of the init latent over `steps` sigmas, every model call tiled through get_noise (upstream :683-743,
+        after the host's img2imgalt script)."""
+        import k_diffusion as K
+        from modules import sd_samplers_common
+        assert self.p.sampler_name == "Euler"
+        x = self.p.init_latent
+        s_in = x.new_ones([x.shape[0]])
+        skip = 1 if shared.sd_model.parameterization == "v" else 0
+        sigmas = dnw.get_sigmas(steps).flip(0)
+        cond = self.p.sd_model.get_learned_conditioning(prompts)
+        if isinstance(cond, Tensor):     # SD1 / SD2
+            cond_in = self.make_cond_dict({"c_crossattn": [], "c_concat": []}, cond, self.p.image_conditioning)
+        else:                            # SDXL
+            cond_in = self.make_cond_dict({"crossattn": None, "vector": None, "c_concat": []}, cond["crossattn"],
+                                          self.p.image_conditioning, cond["vector"])
+        state.sampling_steps = steps
+        try:
+            from tqdm import tqdm
+            bar = tqdm(total=steps, desc="Noise Inversion")
+        except Exception:  # pragma: no cover
+            bar = None
+        for i in range(1, len(sigmas)):
+            if state.interrupted:
+                return x
+            state.sampling_step += 1
+            sigma_in = torch.cat([sigmas[i] * s_in])
+            c_out, c_in = [K.utils.append_dims(k, x.ndim) for k in dnw.get_scalings(sigma_in)[skip:]]
+            t = dnw.sigma_to_t(sigma_in) / self.noise_inverse_retouch
+            eps = self.get_noise(x * c_in, t, cond_in, steps - i)
+            denoised = x + eps * c_out
+            d = (x - denoised) / sigmas[i]            # Euler step towards the next (larger) sigma
+            x = x + d * (sigmas[i] - sigmas[i - 1])
+            sd_samplers_common.store_latent(x)
+            del sigma_in, c_out, c_in, t, eps, denoised, d
+            if bar is not None:
+                bar.update(1)
+        if bar is not None:
+            bar.close()
+        return x / sigmas[-1]
+
+    def get_noise(self, x_in: Tensor, sigma_in: Tensor, cond_in, step: int) -> Tensor:
+        raise NotImplementedError

@@ -7,7 +7,7 @@ computation routed through the mdtile engine (libmdtile.so, include/mdtile.h):
     feather_mask      upstream utils.py:196-214  -> mdtile_feather_mask
 
 Prompt / cond helpers stay thin host-side Python (they only forward to `modules.prompt_parser`).
-`get_retouch_mask` (cv2 guided filter, noise inversion only) is out of scope for this engine.
+`get_retouch_mask` (cv2 guided filter, once per Noise Inversion job on the CPU) is host glue as upstream.
 """
 from __future__ import annotations
 
@@ -183,6 +183,27 @@ def gaussian_weights(tile_w: int, tile_h: int) -> Tensor:
 def feather_mask(w: int, h: int, ratio: float) -> Tensor:
     """Foreground feather mask (upstream utils.py:196-214), generated on the GPU."""
     return mdtile.feather_mask(w, h, ratio, devices.device)
+
+
+NoiseInverseCache = namedtuple("NoiseInversionCache", ["model_hash", "x0", "xt", "noise_inversion_steps", "retouch", "prompts"])
+
+
+def get_retouch_mask(img_input, kernel_size: int):
+    """Where a grey image [H, W] uint8 carries detail: the residue of a self-guided box filter (guided filter with guide = input,
+    eps 0.01), as uint8-quantised fractions in [0, 1] float32 (upstream tile_utils/utils.py:216-247).  Host glue of Noise
+    Inversion: needs OpenCV, runs once per job on the CPU."""
+    import cv2
+    import numpy as np
+    k = (int(round(kernel_size)), int(round(kernel_size)))
+    img = img_input.astype(np.float32) / 255.0
+    mean = cv2.blur(img, k)
+    var = cv2.blur(img * img, k) - mean * mean
+    a = var / (var + 0.01)                 # cov(I, I) / (var(I) + eps)
+    b = mean - a * mean
+    gf = (a * img + b) - img
+    gf *= 255
+    gf = gf.astype(np.uint8)               # upstream quantises (and wraps negatives) exactly like this
+    return gf.clip(0, 255).astype(np.float32) / 255.0
 
 
 def null_decorator(fn):

@@ -245,3 +245,34 @@ def region_noise(org: torch.Tensor, regions) -> torch.Tensor:
     fg = torch.where(fgc > 1, fg / fgc, fg)
     out = torch.where(bgc > 0, bg, org)
     return torch.where(fgc > 0, fg, out)
+
+
+# --------------------------------------------------------------------------------------------------
+# Noise Inversion: renoise composite of sample_img2img  (tile_methods/abstractdiffusion.py:651-676)
+# --------------------------------------------------------------------------------------------------
+def noise_inverse_blend(noise: torch.Tensor, inverse_noise: torch.Tensor, renoise_mask: Optional[torch.Tensor], regions=(),
+                        enable_grid_bbox: bool = True) -> torch.Tensor:
+    """noise / inverse_noise [N,C,H,W]; renoise_mask [H,W] (already strength-scaled and clamped, :612-616) or None;
+    regions: [Region] (rect in latent px, mode, feather ratio).  Restates :655-676 op by op:
+    without a mask the inverse noise is used as is; with the grid disabled the job's noise is first re-weighted by the
+    background hit count and the count-averaged foreground feather masks."""
+    if renoise_mask is None:                                                      # :675-676
+        return inverse_noise
+    if not enable_grid_bbox:                                                      # :658-672
+        H, W = noise.shape[2], noise.shape[3]
+        background_count = torch.zeros((1, 1, H, W))
+        foreground_noise = torch.zeros_like(noise)
+        foreground_weight = torch.zeros((1, 1, H, W))
+        foreground_count = torch.zeros((1, 1, H, W))
+        for r in regions:
+            if r.blend_mode == BG:
+                background_count[r.sl] += 1
+            elif r.blend_mode == FG:
+                foreground_noise[r.sl] += noise[r.sl]
+                foreground_weight[r.sl] += feather_mask(r.w, r.h, r.feather_ratio)
+                foreground_count[r.sl] += 1
+        background_noise = torch.where(background_count > 0, noise, 0)
+        foreground_noise = torch.where(foreground_count > 0, foreground_noise / foreground_count, 0)
+        foreground_weight = torch.where(foreground_count > 0, foreground_weight / foreground_count, 0)
+        noise = background_noise * (1 - foreground_weight) + foreground_noise * foreground_weight
+    return ((1 - renoise_mask) * inverse_noise + renoise_mask * noise) / ((renoise_mask ** 2 + (1 - renoise_mask) ** 2) ** 0.5)

@@ -1,0 +1,100 @@
+"""Single-process multi-rank shard context of the C ABI (csrc/shard.hip) on ONE GPU: the same device listed 2 or 3 times selects the
+copy transport (hipMemcpyAsync + events instead of RCCL) with identical packing and summation, so the whole N-rank flow of
+mdtile/sharding.py::ShardedBlend -- band partition, per-rank partial blends, halo exchange, finalize, region ownership -- is
+checked against the single-device blend.  (The RCCL transport itself needs distinct devices: exercised by bench.py --gpus N.)"""
+import pytest
+import torch
+
+from oracle import blend_oracle as bo
+
+pytestmark = pytest.mark.gpu
+
+
+def _tile_fn(t):
+    return 0.9 * t + 0.1 * t.flip(-1)
+
+
+def _region_fn(t, k):
+    return (0.8 - 0.05 * k) * t + 0.2 * t.flip(-2)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_halo_exchange_sums_in_rank_order(plugin, cuda, world):
+    E = plugin.engine
+    from mdtile import sharding
+    sh = E.Shard(dev_ids=[0] * world)
+    assert (sh.nranks, sh.nlocal, sh.rccl) == (world, world, False)
+    H, W, N, C = 96, 40, 2, 4
+    ys = [0, 20, 40, 60]                         # 4 tile rows of height 36: neighbours overlap by 16 rows
+    bands = sharding.band_partition(ys, 36, 3, H, world)
+    table = sharding.band_rows_table(bands)
+    torch.manual_seed(world)
+    parts = [torch.randn(N, C, H, W, device=cuda) for _ in range(world)]
+    ref = [p.clone() for p in parts]
+    for r in range(world):                        # restatement: shared rows = sum of every toucher's piece, ascending rank
+        for y in range(bands[r].row_lo, bands[r].row_hi):
+            touch = [q for q in range(world) if bands[q].row_lo <= y < bands[q].row_hi]
+            if len(touch) > 1:
+                acc = parts[touch[0]][:, :, y].clone()
+                for q in touch[1:]:
+                    acc = acc + parts[q][:, :, y]
+                ref[r][:, :, y] = acc
+    scratch = sh.halo_scratch(table, N, C, W)
+    sh.halo_exchange(parts, scratch, table, streams=[torch.cuda.current_stream().cuda_stream] * world)
+    torch.cuda.synchronize()
+    for r in range(world):
+        lo, hi = bands[r].row_lo, bands[r].row_hi
+        assert torch.equal(parts[r][:, :, lo:hi], ref[r][:, :, lo:hi])
+    bufs = [torch.full((5,), float(r + 1), dtype=torch.float64, device=cuda) for r in range(world)]
+    sh.allreduce_stats(bufs)
+    assert all(torch.equal(b.cpu(), torch.full((5,), float(sum(range(1, world + 1))), dtype=torch.float64)) for b in bufs)
+
+
+REGIONS = [(4, 6, 30, 20, "Background", 0.2), (20, 30, 36, 28, "Foreground", 0.4), (0, 50, 24, 30, "Background", 0.2)]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("method", ["md", "mod"])
+@pytest.mark.parametrize("with_regions", [False, True])
+def test_sharded_blend_matches_single_device(plugin, cuda, world, method, with_regions):
+    """cfg5 shape class: grid + region prompt control, tiles in row bands and regions dealt to the ranks."""
+    E = plugin.engine
+    from mdtile import sharding
+    W, H, tw, th, ov, bs, N, C = 64, 96, 32, 32, 12, 4, 2, 4
+    M = E.METHOD_MD if method == "md" else E.METHOD_MOD
+    regs = [(x, y, w, h, E.REGION_BG if mode == "Background" else E.REGION_FG, fr) for (x, y, w, h, mode, fr) in REGIONS] if with_regions else []
+    torch.manual_seed(5)
+    x = torch.randn(N, C, H, W, device=cuda)
+    # single-device reference through the same engine calls the delegates make
+    one = sharding.ShardedBlend(E.Shard(dev_ids=[0]), W, H, tw, th, ov, bs, M, regions=regs)
+    ref = one.step([x], _tile_fn, _region_fn)[0].clone()
+    o = bo.BlendOracle(method, W, H, tw, th, ov, bs, [bo.Region(*r) for r in (REGIONS if with_regions else [])], True)
+    want = o.evaluate(x.cpu(), _tile_fn, _region_fn)
+    assert torch.allclose(ref.cpu(), want, rtol=1e-5, atol=1e-6), "one-rank ShardedBlend vs the oracle"
+    sb = sharding.ShardedBlend(E.Shard(dev_ids=[0] * world), W, H, tw, th, ov, bs, M, regions=regs)
+    outs = sb.allgather_rows(sb.step([x.clone() for _ in range(world)], _tile_fn, _region_fn))
+    for r, out in enumerate(outs):
+        assert torch.allclose(out, ref, rtol=1e-5, atol=1e-6), f"rank {r} of {world}: max diff {(out - ref).abs().max().item()}"
+    # rows touched by one band only carry exactly the single-device value (same kernel, same order)
+    for r, b in enumerate(sb.bands):
+        if b.empty:
+            continue
+        solo = [y for y in range(b.row_lo, b.row_hi) if sum(1 for q in sb.bands if not q.empty and q.row_lo <= y < q.row_hi) == 1]
+        if solo and not with_regions:
+            assert torch.equal(outs[r][:, :, solo], ref[:, :, solo])
+
+
+def test_vae_multi_device_sweep_matches_single_device(plugin, cuda):
+    """VAEHook.devices: single-process multi-device decode (tiles dealt round-robin, per-device packed weights and streams, output
+    rectangles copied to the first device).  Listing cuda:0 twice runs the whole flow on one GPU; the result must equal the ordinary
+    sweep bit for bit (same kernels, same frozen statistics)."""
+    from oracle import ldm_decoder as ld
+    dec = ld.make_decoder(4).to(cuda)
+    dec.original_forward = dec.forward
+    torch.manual_seed(13)
+    z = torch.randn(1, 4, 40, 52, device=cuda)
+    hook = plugin.tilevae.VAEHook(dec, 16, is_decoder=True, fast_decoder=True, fast_encoder=False, color_fix=False)
+    one = hook(z).clone()
+    hook.devices = [0, 0, 0]
+    many = hook(z)
+    assert many.device == one.device and torch.equal(many, one)

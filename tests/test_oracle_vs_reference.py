@@ -139,3 +139,179 @@ def test_gn_and_attn_primitives(ref):
     hx = torch.randn(1, 64, 7, 9)
     with torch.no_grad():
         assert torch.equal(ref.attn.attn_forward(ab, hx), vo.attn_body(ab, hx))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Noise Inversion: renoise composite of upstream's sample_img2img (abstractdiffusion.py:606-681) -- the upstream method itself is
+# run under stubs for everything around the composite (cached inversion latent, sigma schedule, retouch mask) and the noise it
+# hands to the original sample_img2img is compared with oracle.noise_inverse_blend.
+# ---------------------------------------------------------------------------------------------------------------------
+NI_REGIONS = [  # x, y, w, h (latent px), mode, feather
+    (3, 2, 20, 12, "Background", 0.2), (10, 6, 18, 14, "Foreground", 0.3), (16, 10, 20, 12, "Foreground", 0.6), (0, 14, 9, 10, "Background", 0.2),
+]
+
+
+def _ni_inputs(W, H, seed=7):
+    g = torch.Generator().manual_seed(seed)
+    noise = torch.randn(2, 4, H, W, generator=g)
+    init_latent = torch.randn(2, 4, H, W, generator=g)
+    xt = torch.randn(2, 4, H, W, generator=g) * 3.0
+    np_mask = torch.rand(H * 8, W * 8, generator=g).numpy()
+    sigmas = torch.linspace(7.5, 0.03, 9)
+    return noise, init_latent, xt, np_mask, sigmas
+
+
+def _ni_mask(np_mask, H, W, strength):
+    import torch.nn.functional as F
+    m = 1 - F.interpolate(torch.from_numpy(np_mask).unsqueeze(0).unsqueeze(0), size=(H, W), mode="bilinear").squeeze(0).squeeze(0)
+    m *= strength
+    return torch.clamp(m, 0, 1)
+
+
+@pytest.mark.parametrize("grid,strength", [(True, 0.7), (False, 0.7), (False, 1.6), (True, 0.0)])
+def test_noise_inverse_composite_bit_exact(ref, grid, strength):
+    from types import SimpleNamespace
+    from PIL import Image
+    absd, utils = ref.abstractdiffusion, ref.utils
+    W, H = 40, 28
+    noise, init_latent, xt, np_mask, sigmas = _ni_inputs(W, H)
+    p = sh.make_processing(W * 8, H * 8)
+    p.init_images = [Image.new("RGB", (W * 8, H * 8))]
+    p.sd_model = SimpleNamespace(sd_model_hash="hash")
+    p.init_latent = init_latent
+    d = ref.multidiffusion.MultiDiffusion(p, sh.kdiff_sampler())
+    if grid:
+        d.init_grid_bbox(16, 16, 4, 2)
+    d.enable_grid_bbox = grid
+    d.custom_bboxes = [utils.CustomBBox(x, y, w, h, "", "", mode, fr, 1) for (x, y, w, h, mode, fr) in NI_REGIONS]
+    d.noise_inverse_steps, d.noise_inverse_retouch = 5, 1.0
+    d.noise_inverse_renoise_strength, d.noise_inverse_renoise_kernel = strength, 3
+    d.noise_inverse_get_cache = lambda: utils.NoiseInverseCache("hash", init_latent.clone(), xt, 5, 1.0, [""])
+    captured = {}
+    d.sample_img2img_original = lambda p_, x_, n_, c_, uc_, steps_, ic_: captured.setdefault("noise", n_)
+    old = (getattr(absd, "get_retouch_mask", None), getattr(absd.sd_samplers_common, "setup_img2img_steps", None))
+    absd.get_retouch_mask = lambda img, k: np_mask
+    absd.sd_samplers_common.setup_img2img_steps = lambda p_, steps: (steps or 8, 6)
+    try:
+        sampler = SimpleNamespace(get_sigmas=lambda p_, steps: sigmas)
+        d.sample_img2img(sampler, p, torch.zeros_like(noise), noise, None, None, steps=8, image_conditioning=None)
+    finally:
+        absd.get_retouch_mask = old[0]
+        if old[1] is None:
+            del absd.sd_samplers_common.setup_img2img_steps
+        else:
+            absd.sd_samplers_common.setup_img2img_steps = old[1]
+    inverse = xt - init_latent / sigmas[0]
+    regs = [bo.Region(x, y, w, h, mode, fr) for (x, y, w, h, mode, fr) in NI_REGIONS]
+    mine = bo.noise_inverse_blend(noise, inverse, _ni_mask(np_mask, H, W, strength) if strength > 0 else None, regs, grid)
+    assert torch.equal(captured["noise"], mine)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Region forwards: the product's kdiff_custom_forward / ddim_custom_forward against upstream's under every batching mode of the
+# host's CFG denoiser (whole batch, prompts of different token length, partial batches, edit model).  Pure host logic: runs
+# without the engine.  The "model" records (rows, prompt rows) per call and returns a function of both, so routing errors show.
+# ---------------------------------------------------------------------------------------------------------------------
+def _fake_forward(calls):
+    def f(x, sigma, cond):
+        t = cond["c_crossattn"][0] if isinstance(cond["c_crossattn"], list) else cond["c_crossattn"]
+        assert t.shape[0] == x.shape[0] == sigma.shape[0], f"batch mismatch: x {x.shape[0]} cond {t.shape[0]} sigma {sigma.shape[0]}"
+        calls.append((x.shape[0], t.shape[1]))
+        return x * 0.5 + t.mean(dim=(1, 2)).view(-1, 1, 1, 1) + sigma.view(-1, 1, 1, 1)
+    return f
+
+
+def _drive_custom_forward(mods, lens, chunks, batch_cond_uncond, edit, glob=(77, 77)):
+    """mods: namespace with multidiffusion / utils (reference or product).  lens = (region prompt tokens, region negative tokens);
+    chunks = row counts of the successive model calls of one sampler step."""
+    from types import SimpleNamespace
+    _, shared = sh.host()
+    old_bcu = getattr(shared, "batch_cond_uncond", True)
+    shared.batch_cond_uncond = batch_cond_uncond
+    cls = mods.multidiffusion.MultiDiffusion
+    _missing = object()
+    old_edit = cls.__dict__.get("is_edit_model", _missing)
+    cls.is_edit_model = edit
+    C = mods.utils.Condition
+    old_rc, old_ru = C.reconstruct_cond, C.reconstruct_uncond
+    g = torch.Generator().manual_seed(5)
+    tens = {"gc": torch.randn(1, glob[0], 8, generator=g), "gu": torch.randn(1, glob[1], 8, generator=g),
+            "rc": torch.randn(1, lens[0], 8, generator=g), "ru": torch.randn(1, lens[1], 8, generator=g)}
+    C.reconstruct_cond = staticmethod(lambda c, step: tens[c])
+    C.reconstruct_uncond = staticmethod(lambda c, step: tens[c])
+    try:
+        p = sh.make_processing(64 * 8, 48 * 8)
+        smp = sh.kdiff_sampler()
+        smp.model_wrap_cfg = SimpleNamespace(step=3, inner_model=SimpleNamespace(forward=None), image_cfg_scale=None)
+        d = cls(p, smp)
+        d.custom_bboxes = [mods.utils.CustomBBox(4, 4, 16, 12, "", "", "Background", 0.2, 1)]
+        d.custom_bboxes[0].cond, d.custom_bboxes[0].uncond = "rc", "ru"
+        d.cond_basis, d.uncond_basis = "gc", "gu"
+        calls, outs = [], []
+        total = sum(chunks)
+        x = torch.randn(total, 4, 12, 16, generator=g)
+        sig = torch.rand(total, generator=g)
+        cond = {"c_crossattn": [torch.zeros(total, 77, 8)], "c_concat": [torch.zeros(total, 5, 1, 1)]}
+        a = 0
+        for n in chunks:
+            sub = {"c_crossattn": [cond["c_crossattn"][0][a:a + n]], "c_concat": [cond["c_concat"][0][a:a + n]]}
+            outs.append(d.kdiff_custom_forward(x[a:a + n], sig[a:a + n], sub, 0, d.custom_bboxes[0], _fake_forward(calls)))
+            a += n
+        return torch.cat(outs), calls
+    finally:
+        C.reconstruct_cond, C.reconstruct_uncond = old_rc, old_ru
+        if old_edit is _missing:
+            del cls.is_edit_model
+        else:
+            cls.is_edit_model = old_edit
+        shared.batch_cond_uncond = old_bcu
+
+
+KDIFF_CASES = [  # (region prompt tokens, region negative tokens), chunks, batch_cond_uncond, edit, global token lengths
+    ((77, 77), [2], True, False, (77, 77)),        # whole batch, equal lengths: one call
+    ((154, 77), [2], True, False, (77, 77)),       # region prompt > 75 tokens: two calls
+    ((77, 77), [3], True, True, (77, 77)),         # edit model: [cond, uncond, uncond]
+    ((154, 77), [3], True, True, (77, 77)),        # edit model + different lengths
+    ((77, 77), [1, 1], False, False, (77, 77)),    # batch_cond_uncond off: cond, then uncond
+    ((154, 77), [1, 1], False, False, (77, 77)),
+    ((77, 77), [1, 1], True, False, (154, 77)),    # GLOBAL prompts of different length: the host itself splits
+]
+
+
+@pytest.mark.parametrize("lens,chunks,bcu,edit,glob", KDIFF_CASES)
+def test_kdiff_custom_forward_matches_upstream(ref, lens, chunks, bcu, edit, glob):
+    want, calls_ref = _drive_custom_forward(ref, lens, chunks, bcu, edit, glob)
+    got, calls = _drive_custom_forward(sh.load_plugin(), lens, chunks, bcu, edit, glob)
+    assert calls == calls_ref, f"model calls (rows, tokens): product {calls} vs upstream {calls_ref}"
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("lens", [(77, 77), (154, 77), (77, 154)])
+def test_ddim_custom_forward_matches_upstream(ref, lens):
+    from types import SimpleNamespace
+    outs = []
+    for mods in (ref, sh.load_plugin()):
+        C = mods.utils.Condition
+        old_rc, old_ru = C.reconstruct_cond, C.reconstruct_uncond
+        g = torch.Generator().manual_seed(9)
+        tens = {"rc": torch.randn(1, lens[0], 8, generator=g), "ru": torch.randn(1, lens[1], 8, generator=g)}
+        C.reconstruct_cond = staticmethod(lambda c, step: tens[c])
+        C.reconstruct_uncond = staticmethod(lambda c, step: tens[c])
+        try:
+            smp = sh.kdiff_sampler()
+            smp.model_wrap_cfg = SimpleNamespace(step=3, inner_model=SimpleNamespace(forward=None), image_cfg_scale=None)
+            d = mods.multidiffusion.MultiDiffusion(sh.make_processing(512, 384), smp)
+            bbox = mods.utils.CustomBBox(4, 4, 16, 12, "", "", "Background", 0.2, 1)
+            bbox.cond, bbox.uncond = "rc", "ru"
+            seen = {}
+
+            def fwd(x, c, ts, unconditional_conditioning):
+                seen["c"], seen["uc"] = c, unconditional_conditioning
+                return x
+            cond_in = {"c_crossattn": [torch.zeros(1, 77, 8)], "c_concat": [torch.zeros(1, 5, 1, 1)]}
+            d.ddim_custom_forward(torch.zeros(1, 4, 12, 16), cond_in, bbox, torch.zeros(1), fwd)
+            outs.append((seen["c"]["c_crossattn"][0], seen["uc"]["c_crossattn"][0]))
+        finally:
+            C.reconstruct_cond, C.reconstruct_uncond = old_rc, old_ru
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert outs[1][0].shape[1] == outs[1][1].shape[1]
