@@ -16,12 +16,13 @@
 //                   the probabilities go from the score MFMAs to the output MFMAs without any cross-lane movement.
 //   k_attn_bf16x3<C>  block = 512 threads (8 waves), 128 queries; per 128-key block:
 //        scores  St[key][query] = sum_c K[key][c] Q[query][c]   A = K (M = keys), B = Q (N = queries), K-dim = channels;
-//                wave w owns key tile w >> 1 and the two query tiles of half w & 1; channels stream in 32-channel slabs
+//                wave w owns key tile w >> 1 and the two query tiles of half w & 1; channels stream in 64-channel slabs
 //        softmax a lane holds one query column (16 keys of its tile): max / sum in-lane + one 32-lane swap, the 4 key
 //                tiles of a query are combined through a few hundred bytes of LDS; P -> bf16 hi/lo records in LDS
 //        output  Ot[c][query] += sum_key V[key][c] P[key][query]   A = V^T (M = channels), B = P^T, K-dim = keys;
-//                the 128 x C output block lives in registers (8 waves x 8 accumulator tiles for C = 512)
-//   LDS: two 32 KB slab buffers (K+Q slabs, then V slabs; register-prefetched, ONE barrier per slab) + 64 KB P + statistics.
+//                the 128 x C output block lives in registers (8 waves x 8 accumulator tiles for C = 512); the V^T fragments
+//                of a wave are its own (nobody shares them) and come straight from global memory
+//   LDS: two 64 KB slab stages (K + Q slabs by DMA; the P records of a key block overlay the stage that is free) + statistics.
 #include "common.h"
 
 using namespace mdt;
@@ -33,7 +34,6 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int BQ = 128, BK = 128;        // queries per block, keys per iteration
-constexpr int SLAB_REC = 2048;           // 16-byte records per slab buffer (32 KB)
 constexpr int P_REC = 8 * 4 * 2 * 64;    // [key k-step 8][query tile 4][hl][lane]
 constexpr int STAT_FLOATS = 4 * BQ + 4 * BQ + BQ;   // smax[4][128], ssum[4][128], alpha[128]
 
@@ -98,25 +98,42 @@ __global__ __launch_bounds__(256) void k_attn_prep_v(const float* __restrict__ s
     d[64 + lane] = lo;
 }
 
-// DMA = true: the K/Q/V slabs go global -> LDS directly (global_load_lds_dwordx4: the fragment-order records are straight
-// copies, so a wave's 64 records land as one contiguous 1 KiB run); no staging VGPRs and no ds_write_b128 pass (13 LDS cycles
-// per wave-instruction on the store path -- the score phase was LDS-write bound).  Same two-buffer schedule: the DMA of
-// slab i+1 is issued right after the barrier that opens slab i and is drained (vmcnt(0)) before the barrier that opens i+1.
-template <int C, bool DMA>
-__global__ __launch_bounds__(512) void k_attn_bf16x3(const u32x4* __restrict__ Qr, const u32x4* __restrict__ Kr, const u32x4* __restrict__ Vr,
-                                                     float* __restrict__ out, int T, int T128, int Tk, int Tk128, float scale, int nsplit,
-                                                     float* __restrict__ part, float* __restrict__ pstat) {
+// LDS-DMA of one 16-byte record per lane (global scalar base + 32-bit lane offset -> LDS wave-uniform base + 16 * lane), issued
+// through inline asm: hipcc books __builtin_amdgcn_global_load_lds as a pending FLAT access and then turns every later
+// `s_waitcnt lgkmcnt(N)` into lgkmcnt(0), which would serialise the fragment prefetch below (same finding as vae_conv_rec.hip).
+// Completion is counted by hand: vmcnt(0) + barrier before any ds_read of the data.
+__device__ __forceinline__ void dma16a(const void* base, unsigned voff, const u32x4* lds_dst) {
+    const unsigned l = (unsigned)(__UINTPTR_TYPE__)(const __attribute__((address_space(3))) u32x4*)lds_dst;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(base), "s"(l)
+                 : "memory");
+}
+
+#define MDT_PIN() __builtin_amdgcn_sched_barrier(0)
+
+// One 128-query block against its key range, per 128-key block:
+//   scores   channels stream through LDS in 64-channel slabs [K | Q][tile 4][ks 4][hl][lane] (64 KB) by DMA, two stages; the
+//            fragments of k-step ks+1 are read while the MFMAs of ks run (two register sets); ONE barrier per slab (24 MFMAs / wave)
+//   softmax  as before; the P records (64 KB) are written INTO the slab stage that is free at that point (no LDS of their own)
+//   output   V^T fragments are private to a wave (it owns MT_W channel tiles): they go global -> registers directly, two 16-key
+//            steps ahead, never through LDS; P fragments are read one half-step ahead.  No barrier inside the output phase.
+// 10 barriers per key block (8 slabs + 2 in the softmax) against 26 of the slab-per-32-channels / V-through-LDS schedule.
+template <int C>
+__global__ __launch_bounds__(512, 2) void k_attn_bf16x3(const u32x4* __restrict__ Qr, const u32x4* __restrict__ Kr, const u32x4* __restrict__ Vr,
+                                                        float* __restrict__ out, int T, int T128, int Tk, int Tk128, float scale, int nsplit,
+                                                        float* __restrict__ part, float* __restrict__ pstat) {
     // T / T128: QUERY tokens (rows of the output); Tk / Tk128: KEY tokens.  They differ only when a row band of the queries
     // attends to keys / values gathered from every band (sequence-parallel estimator, mdtile/seqpar.py).
-    constexpr int NKS = C / 16, NMT = C / 32, NSS = NKS / 2;        // channel k-steps, 32-channel output tiles, score slabs
+    constexpr int NKS = C / 16, NMT = C / 32, KSS = 4, NSS = NKS / KSS;     // channel k-steps, 32-channel output tiles, k-steps / slab, slabs
     constexpr int WAVES_M = NMT < 8 ? NMT : 8, WAVES_N = 8 / WAVES_M, MT_W = NMT / WAVES_M, NT_W = 4 / WAVES_N;
-    constexpr int PV_REC = NMT * 2 * 64;                            // records of one V slab (16 keys)
-    constexpr int NVREG = (PV_REC + 511) / 512;
-    static_assert(PV_REC <= SLAB_REC && NSS >= 1, "slab sizing");
-    __shared__ u32x4 smem[2 * SLAB_REC + P_REC + STAT_FLOATS / 4];
+    constexpr int HALF_REC = 4 * KSS * 2 * 64;                              // K (or Q) part of a slab: [tile 4][ks][hl][lane]
+    constexpr int STAGE_REC = 2 * HALF_REC;                                 // 4096 records = 64 KB = exactly the P records of a key block
+    static_assert(NSS >= 2 && NSS % 2 == 0 && STAGE_REC == P_REC, "slab sizing");
+    __shared__ u32x4 smem[2 * STAGE_REC + STAT_FLOATS / 4];
     u32x4* const slab = smem;
-    u32x4* const p_l = smem + 2 * SLAB_REC;
-    float* const smax = reinterpret_cast<float*>(smem + 2 * SLAB_REC + P_REC);
+    float* const smax = reinterpret_cast<float*>(smem + 2 * STAGE_REC);
     float* const ssum = smax + 4 * BQ;
     float* const salpha = ssum + 4 * BQ;
 
@@ -125,10 +142,7 @@ __global__ __launch_bounds__(512) void k_attn_bf16x3(const u32x4* __restrict__ Q
     const int kt_w = wave >> 1, qh = wave & 1;                      // score phase: key tile, query-tile pair
     const int wm = wave % WAVES_M, wn = wave / WAVES_M;             // output phase: channel tiles, query tiles
     // block -> (query block, key split), XCD-aware: workgroups go to XCDs round-robin (id % 8), so the `nsplit` key ranges of one
-    // query block are handed to consecutive slots of ONE XCD.  Each of them re-streams the same Q records (256 KB at C = 512)
-    // once per key block; with 32 / nsplit distinct query blocks per XCD that working set (2 MB at nsplit = 4) stays in the
-    // 4 MB L2 instead of being re-fetched from the Infinity Cache 600 times (measured: 96 GB of fabric traffic per 77k-token
-    // tile = exactly the Q re-reads, profiles/r1h/pmc_hbm_summary.json).
+    // query block are handed to consecutive slots of ONE XCD: the Q records every key block re-streams stay in that XCD's L2.
     const int b = blockIdx.y;
     const int bid = blockIdx.x, bxcd = bid & 7, bslot = bid >> 3;
     const int qb = (bslot / nsplit) * 8 + bxcd;
@@ -139,50 +153,19 @@ __global__ __launch_bounds__(512) void k_attn_bf16x3(const u32x4* __restrict__ Q
     const u32x4* Kb = Kr + (size_t)b * ktiles * NKS * 128;
     const u32x4* Vb = Vr + (size_t)b * groups * NMT * 128;
 
-    u32x4 rg[DMA ? 1 : 4];
-    // score slab s of key block kb: records [K | Q][tile 4][ks 2][hl][lane]; source = 4 + 4 runs of 256 contiguous records.
-    // `into`: the slab buffer the data is meant for (DMA writes it now; the register path writes it in write_S/V).
-    auto issue_S = [&](int kb, int s, int into) {
+    // slab s of key block kb -> stage: 8 DMA pieces per wave (4 K + 4 Q); piece i covers records [512 (wave/2*... see below)
+    // source of tile t, slab s: KSS * 2 * 64 = 512 contiguous records at ((t * NKS + KSS * s) * 128); a wave-instruction moves 64
+    // of them: piece index d in [0, 32) of a half -> tile d >> 3, records (d & 7) * 64 .. + 64
+    const unsigned lane16 = lane * 16;
+    auto issue_S = [&](int kb, int s, int stage) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = tid + 512 * i;                 // i < 2: K part, i >= 2: Q part (compile-time)
-            const int rr = r & 1023, t4 = rr >> 8, off = rr & 255;
-            const u32x4* src = (i < 2 ? Kb + ((size_t)(kb * 4 + t4) * NKS + 2 * s) * 128 : Qb + ((size_t)t4 * NKS + 2 * s) * 128) + off;
-            if (DMA)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(slab + into * SLAB_REC + wave * 64 + 512 * i), 16, 0, 0);
-            else
-                rg[DMA ? 0 : i] = *src;
+        for (int i = 0; i < 8; ++i) {
+            const int half = i >> 2;                     // 0: K, 1: Q (compile-time)
+            const int d = wave * 4 + (i & 3);            // 0 .. 31
+            const int t4 = d >> 3, off = (d & 7) * 64;
+            const u32x4* src = (half == 0 ? Kb + ((size_t)(kb * 4 + t4) * NKS + KSS * s) * 128 : Qb + ((size_t)t4 * NKS + KSS * s) * 128) + off;
+            dma16a(src, lane16, slab + stage * STAGE_REC + half * HALF_REC + d * 64);
         }
-    };
-    auto issue_V = [&](int kb, int p, int into) {
-        const u32x4* src = Vb + (size_t)(kb * 8 + p) * NMT * 128;
-#pragma unroll
-        for (int i = 0; i < NVREG; ++i)
-            if (wave * 64 + 512 * i < PV_REC) {
-                if (DMA)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + tid + 512 * i),
-                                                     (__attribute__((address_space(3))) void*)(slab + into * SLAB_REC + wave * 64 + 512 * i), 16, 0, 0);
-                else
-                    rg[DMA ? 0 : i] = src[tid + 512 * i];
-            }
-    };
-    auto write_S = [&](int buf) {
-        if (DMA) {
-            __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): this wave's share of the slab has landed in LDS
-            return;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) slab[buf * SLAB_REC + tid + 512 * i] = rg[DMA ? 0 : i];
-    };
-    auto write_V = [&](int buf) {
-        if (DMA) {
-            __builtin_amdgcn_s_waitcnt(0x0F70);
-            return;
-        }
-#pragma unroll
-        for (int i = 0; i < NVREG; ++i)
-            if (wave * 64 + 512 * i < PV_REC) slab[buf * SLAB_REC + tid + 512 * i] = rg[DMA ? 0 : i];
     };
 
     f32x16 acc_o[MT_W][NT_W];
@@ -194,11 +177,9 @@ __global__ __launch_bounds__(512) void k_attn_bf16x3(const u32x4* __restrict__ Q
             for (int r = 0; r < 16; ++r) acc_o[m][n][r] = 0.0f;
     float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.0f, 0.0f};   // for queries (2*qh + j)*32 + l31
 
-    // key-range split: with 1 block per CU a 604-block launch leaves the last of its 3 rounds 2/3 empty; splitting
-    // every query block's keys nsplit ways evens the rounds out.  Each part keeps its own running (max, sum) and an
-    // un-normalised output; k_attn_combine merges them.
+    // key-range split: each part keeps its own running (max, sum) and an un-normalised output; k_attn_combine merges them
     const int kb_lo = (int)((long long)nkb * split / nsplit), kb_hi = (int)((long long)nkb * (split + 1) / nsplit);
-    int buf = 0;
+    int base = 0;                                  // stage of slab 0 of the current key block; slab s sits in stage (base + s) & 1
     issue_S(kb_lo, 0, 0);
     for (int kb = kb_lo; kb < kb_hi; ++kb) {
         // ------------------------------------------------ scores: St tiles (kt_w, 2*qh + j), all channels
@@ -207,29 +188,52 @@ __global__ __launch_bounds__(512) void k_attn_bf16x3(const u32x4* __restrict__ Q
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[j][r] = 0.0f;
+        bf16x8 fa[2][2], fb[2][2][2];              // [set][hl], [set][j][hl]
 #pragma unroll 1
         for (int s = 0; s < NSS; ++s) {
-            write_S(buf);
-            __syncthreads();
-            if (s + 1 < NSS) issue_S(kb, s + 1, buf ^ 1);
-            else issue_V(kb, 0, buf ^ 1);
-            const u32x4* sl = slab + buf * SLAB_REC;
+            const int stage = (base + s) & 1;
+            __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0): this wave's pieces of slab s have landed
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            // the other stage is free now (slab s-1 / the previous block's P are consumed by every wave): next slab goes out
+            if (s + 1 < NSS) issue_S(kb, s + 1, stage ^ 1);
+            const u32x4* ka = slab + stage * STAGE_REC + (kt_w * KSS * 2) * 64 + lane;
+            const u32x4* qa = slab + stage * STAGE_REC + HALF_REC + (2 * qh * KSS * 2) * 64 + lane;
+            auto load_ks = [&](int set, int ks) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 ah = __builtin_bit_cast(bf16x8, sl[((kt_w * 2 + ks) * 2 + 0) * 64 + lane]);
-                const bf16x8 al = __builtin_bit_cast(bf16x8, sl[((kt_w * 2 + ks) * 2 + 1) * 64 + lane]);
+                for (int hl = 0; hl < 2; ++hl) {
+                    fa[set][hl] = __builtin_bit_cast(bf16x8, ka[(ks * 2 + hl) * 64]);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int qt = 2 * qh + j;
-                    const bf16x8 bh = __builtin_bit_cast(bf16x8, sl[1024 + ((qt * 2 + ks) * 2 + 0) * 64 + lane]);
-                    const bf16x8 bl = __builtin_bit_cast(bf16x8, sl[1024 + ((qt * 2 + ks) * 2 + 1) * 64 + lane]);
-                    st[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, st[j], 0, 0, 0);
-                    st[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, st[j], 0, 0, 0);
-                    st[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, st[j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) fb[set][j][hl] = __builtin_bit_cast(bf16x8, qa[((j * KSS + ks) * 2 + hl) * 64]);
                 }
+            };
+            load_ks(0, 0);
+#pragma unroll
+            for (int ks = 0; ks < KSS; ++ks) {
+                const int set = ks & 1;
+                MDT_PIN();
+                if (ks + 1 < KSS) load_ks(set ^ 1, ks + 1);
+                MDT_PIN();
+#pragma unroll
+                for (int term = 0; term < 3; ++term)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        st[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][term == 0 ? 1 : 0], fb[set][j][term == 1 ? 1 : 0], st[j], 0, 0, 0);
+                MDT_PIN();
             }
-            buf ^= 1;
         }
+        // ------------------------------------------------ V^T fragments of the first two 16-key steps go out now (latency under the softmax)
+        const u32x4* vsrc = Vb + ((size_t)kb * 8 * NMT + wm * MT_W) * 128 + lane;      // + p * NMT * 128 + (m * 2 + hl) * 64
+        u32x4 fv[3][MT_W][2];
+        auto load_v = [&](int set, int p) {
+#pragma unroll
+            for (int m = 0; m < MT_W; ++m)
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl) fv[set][m][hl] = vsrc[(size_t)p * NMT * 128 + (m * 2 + hl) * 64];
+        };
+        load_v(0, 0);
+        load_v(1, 1);
         // ------------------------------------------------ online softmax (lane = query column, 16 keys of tile kt_w per j)
         const int key0 = kb * BK + kt_w * 32 + 4 * kg;
         float mx[2];
@@ -247,7 +251,15 @@ __global__ __launch_bounds__(512) void k_attn_bf16x3(const u32x4* __restrict__ Q
             mx[j] = m;
             if (kg == 0) smax[kt_w * BQ + (2 * qh + j) * 32 + l31] = m;
         }
-        __syncthreads();
+        // raw barrier + lgkmcnt(0) only: __syncthreads() would also drain vmcnt, i.e. the V^T prefetch just issued (and, further
+        // down, the next slab's DMA).  (Also: every wave is done with the last slab.)
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // the stage of the last slab is free: the next key block's slab 0 goes there and lands under the softmax + output phase
+        if (kb + 1 < kb_hi) issue_S(kb + 1, 0, base ^ 1);
+        u32x4* const p_l = slab + base * STAGE_REC;  // P records of this key block: the stage slab NSS-2 sat in
         float alpha[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -282,13 +294,16 @@ __global__ __launch_bounds__(512) void k_attn_bf16x3(const u32x4* __restrict__ Q
                 d[64 + lane] = lo;
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): P records and the partial sums are written
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int q = (2 * qh + j) * 32 + l31;
             l_run[j] = l_run[j] * alpha[j] + ((ssum[q] + ssum[BQ + q]) + (ssum[2 * BQ + q] + ssum[3 * BQ + q]));
         }
-        // ------------------------------------------------ output: rescale, then Ot += V^T P^T over the 128 keys
+        // ------------------------------------------------ output: rescale, then Ot += V^T P^T over the 128 keys (no barrier inside)
 #pragma unroll
         for (int n = 0; n < NT_W; ++n) {
             const float a = salpha[(wn * NT_W + n) * 32 + l31];
@@ -297,33 +312,38 @@ __global__ __launch_bounds__(512) void k_attn_bf16x3(const u32x4* __restrict__ Q
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc_o[m][n][r] *= a;
         }
-#pragma unroll 1
+        constexpr int HN = NT_W >= 2 ? NT_W / 2 : 1, NH = NT_W / HN;     // query tiles per half-step, half-steps per 16-key step
+        bf16x8 fp[2][HN][2];                                              // [set][n][hl]
+        auto load_p = [&](int set, int p, int h) {
+#pragma unroll
+            for (int n = 0; n < HN; ++n)
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl)
+                    fp[set][n][hl] = __builtin_bit_cast(bf16x8, p_l[((p * 4 + wn * NT_W + h * HN + n) * 2 + hl) * 64 + lane]);
+        };
+        load_p(0, 0, 0);
+#pragma unroll
         for (int p = 0; p < 8; ++p) {
-            write_V(buf);
-            __syncthreads();
-            if (p + 1 < 8) issue_V(kb, p + 1, buf ^ 1);
-            else if (kb + 1 < kb_hi) issue_S(kb + 1, 0, buf ^ 1);
-            const u32x4* sl = slab + buf * SLAB_REC;
-            bf16x8 vh[MT_W], vl[MT_W];
+            const int vs = p % 3;
+            if (p + 2 < 8) load_v((p + 2) % 3, p + 2);
 #pragma unroll
-            for (int m = 0; m < MT_W; ++m) {
-                vh[m] = __builtin_bit_cast(bf16x8, sl[((wm * MT_W + m) * 2 + 0) * 64 + lane]);
-                vl[m] = __builtin_bit_cast(bf16x8, sl[((wm * MT_W + m) * 2 + 1) * 64 + lane]);
+            for (int h = 0; h < NH; ++h) {
+                const int t = p * NH + h, ps_ = t & 1;
+                MDT_PIN();
+                if (t + 1 < 8 * NH) load_p(ps_ ^ 1, (t + 1) / NH, (t + 1) % NH);
+                MDT_PIN();
+#pragma unroll
+                for (int term = 0; term < 3; ++term)
+#pragma unroll
+                    for (int n = 0; n < HN; ++n)
+#pragma unroll
+                        for (int m = 0; m < MT_W; ++m)
+                            acc_o[m][h * HN + n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                __builtin_bit_cast(bf16x8, fv[vs][m][term == 0 ? 1 : 0]), fp[ps_][n][term == 1 ? 1 : 0], acc_o[m][h * HN + n], 0, 0, 0);
+                MDT_PIN();
             }
-#pragma unroll
-            for (int n = 0; n < NT_W; ++n) {
-                const u32x4* pr = p_l + ((p * 4 + wn * NT_W + n) * 2) * 64;
-                const bf16x8 ph = __builtin_bit_cast(bf16x8, pr[lane]);
-                const bf16x8 pl = __builtin_bit_cast(bf16x8, pr[64 + lane]);
-#pragma unroll
-                for (int m = 0; m < MT_W; ++m) {
-                    acc_o[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl[m], ph, acc_o[m][n], 0, 0, 0);
-                    acc_o[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[m], pl, acc_o[m][n], 0, 0, 0);
-                    acc_o[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[m], ph, acc_o[m][n], 0, 0, 0);
-                }
-            }
-            buf ^= 1;
         }
+        base ^= 1;
     }
 
     // ---------------------------------------------------- normalise by the softmax denominator and store [B, C, T]
@@ -470,10 +490,10 @@ int attn_bf16x3_launch(const float* d_q, const float* d_k, const float* d_v_tok,
     MDT_LAUNCH_CHECK();
     const int nq8 = (Tq128 / BQ + 7) / 8 * 8;
     dim3 grid(nq8 * ns, B), block(512);
-#define MDT_ATTN_LAUNCH(CC, DD) hipLaunchKernelGGL((k_attn_bf16x3<CC, DD>), grid, block, 0, s, Qr, Kr, Vr, d_out, Tq, Tq128, Tk, Tk128, scale, ns, part, pstat)
-    if (C == 512) MDT_ATTN_LAUNCH(512, true);
-    else if (C == 256) MDT_ATTN_LAUNCH(256, true);
-    else MDT_ATTN_LAUNCH(128, true);
+#define MDT_ATTN_LAUNCH(CC) hipLaunchKernelGGL((k_attn_bf16x3<CC>), grid, block, 0, s, Qr, Kr, Vr, d_out, Tq, Tq128, Tk, Tk128, scale, ns, part, pstat)
+    if (C == 512) MDT_ATTN_LAUNCH(512);
+    else if (C == 256) MDT_ATTN_LAUNCH(256);
+    else MDT_ATTN_LAUNCH(128);
 #undef MDT_ATTN_LAUNCH
     MDT_LAUNCH_CHECK();
     if (ns > 1) {

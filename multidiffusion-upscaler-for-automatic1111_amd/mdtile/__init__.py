@@ -401,37 +401,75 @@ def _regions_array(regions: Sequence[RegionSpec], dtype):
     return arr, keep
 
 
+class BlendCall:
+    """A fully marshalled mdtile_blend call: the argument struct, the batch-pointer array and the region array are built ONCE; calling
+    the object only does the C call (a few microseconds of host time instead of rebuilding ~10 ctypes objects per evaluation -- the
+    blend itself runs 20 us on an 8K canvas).  Valid while the tensors it was built from stay alive at the same addresses (sampler
+    loops that write the model outputs into fixed buffers; bench.py)."""
+
+    __slots__ = ("plan", "out", "_a", "_ptrs", "_n", "_rarr", "_nreg", "_keep", "_fn")
+
+    def __init__(self, plan: Plan, method: int, batch_out: Sequence[torch.Tensor], N: int, C: int, *, weights=None, tile_w=None, rescale=None,
+                 regions: Sequence[RegionSpec] = (), out: Optional[torch.Tensor] = None, dtype=None, device=None, partial: bool = False,
+                 tile_range=None, row_range=None, packed: bool = False):
+        if len(batch_out):
+            dtype, device = batch_out[0].dtype, batch_out[0].device
+        elif len(regions):
+            dtype, device = regions[0].out.dtype, regions[0].out.device
+        assert dtype is not None and device is not None
+        for i, t in enumerate(batch_out):
+            _dev_tensor(t, f"batch_out[{i}]", dtype)
+        flags = (BLEND_PARTIAL if partial else 0) | (BLEND_PACKED if packed else 0) | (BLEND_TILE_RANGE if tile_range is not None else 0)
+        if out is None:
+            out = torch.empty((N, C, plan.h, plan.w), dtype=torch.float32 if partial else dtype, device=device)
+        _dev_tensor(out, "out", torch.float32 if partial else dtype)
+        for nm, t in (("weights", weights), ("tile_w", tile_w), ("rescale", rescale)):
+            if t is not None:
+                _dev_tensor(t, nm, torch.float32)
+        self.plan, self.out = plan, out
+        self._a = _BlendArgs(method, dtype_code(dtype), N, C, flags, *(tile_range or (0, 0)), *(row_range or (0, 0)),
+                             _p(weights).value, _p(tile_w).value, _p(rescale).value, out.data_ptr())
+        self._ptrs = (c_void_p * max(1, len(batch_out)))(*[t.data_ptr() for t in batch_out])
+        self._n = len(batch_out)
+        self._rarr, keep = _regions_array(regions, dtype)
+        self._nreg = len(regions)
+        self._keep = (list(batch_out), weights, tile_w, rescale, keep)
+        self._fn = lib().mdtile_blend
+
+    def __call__(self) -> torch.Tensor:
+        rc = self._fn(self.plan.handle, ctypes.byref(self._a), self._ptrs, self._n, self._rarr, self._nreg, _stream())
+        if rc != OK:
+            _check(rc, "mdtile_blend")
+        return self.out
+
+
 def blend(plan: Plan, method: int, batch_out: Sequence[torch.Tensor], N: int, C: int, *, weights=None, tile_w=None,
           rescale=None, regions: Sequence[RegionSpec] = (), out: Optional[torch.Tensor] = None, dtype=None, device=None,
           partial: bool = False, tile_range=None, row_range=None, packed: bool = False) -> torch.Tensor:
     """One fused launch replacing the scatter/normalise/feather op sequence of sample_one_step / apply_model_hijack."""
-    if len(batch_out):
-        dtype = batch_out[0].dtype
-        device = batch_out[0].device
-    elif len(regions):
-        dtype, device = regions[0].out.dtype, regions[0].out.device
-    assert dtype is not None and device is not None
-    for i, t in enumerate(batch_out):
-        _dev_tensor(t, f"batch_out[{i}]", dtype)
-    flags = 0
-    if partial:
-        flags |= BLEND_PARTIAL
-    if packed:
-        flags |= BLEND_PACKED
-    if tile_range is not None:
-        flags |= BLEND_TILE_RANGE
-    if out is None:
-        out = torch.empty((N, C, plan.h, plan.w), dtype=torch.float32 if partial else dtype, device=device)
-    _dev_tensor(out, "out", torch.float32 if partial else dtype)
-    for nm, t in (("weights", weights), ("tile_w", tile_w), ("rescale", rescale)):
-        if t is not None:
-            _dev_tensor(t, nm, torch.float32)
-    a = _BlendArgs(method, dtype_code(dtype), N, C, flags, *(tile_range or (0, 0)), *(row_range or (0, 0)),
-                   _p(weights).value, _p(tile_w).value, _p(rescale).value, out.data_ptr())
-    ptrs = (c_void_p * max(1, len(batch_out)))(*[t.data_ptr() for t in batch_out])
-    rarr, _keep = _regions_array(regions, dtype)
-    _check(lib().mdtile_blend(plan.handle, ctypes.byref(a), ptrs, len(batch_out), rarr, len(regions), _stream()), "mdtile_blend")
-    return out
+    return BlendCall(plan, method, batch_out, N, C, weights=weights, tile_w=tile_w, rescale=rescale, regions=regions, out=out, dtype=dtype,
+                     device=device, partial=partial, tile_range=tile_range, row_range=row_range, packed=packed)()
+
+
+class GatherRangeCall:
+    """Marshalled mdtile_gather_range (tiles [tile_lo, tile_hi) into a packed buffer), see BlendCall."""
+
+    __slots__ = ("_args", "_fn", "_keep", "packed")
+
+    def __init__(self, plan: Plan, x_in: torch.Tensor, packed: torch.Tensor, tile_lo: int, tile_hi: int):
+        _dev_tensor(x_in, "x_in")
+        _dev_tensor(packed, "packed", x_in.dtype)
+        N, C, H, W = x_in.shape
+        assert (H, W) == (plan.h, plan.w) and packed.numel() == plan.num_tiles * N * C * plan.tile_h * plan.tile_w
+        self._args = (plan.handle, dtype_code(x_in.dtype), N, C, _p(x_in), _p(packed), int(tile_lo), int(tile_hi))
+        self._fn = lib().mdtile_gather_range
+        self._keep, self.packed = (plan, x_in), packed
+
+    def __call__(self) -> torch.Tensor:
+        rc = self._fn(*self._args, _stream())
+        if rc != OK:
+            _check(rc, "mdtile_gather_range")
+        return self.packed
 
 
 def blend_finalize(plan: Plan, method: int, partial: torch.Tensor, *, weights=None, regions: Sequence[RegionSpec] = (),

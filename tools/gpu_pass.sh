@@ -9,6 +9,7 @@ O=$R/gpurun_out
 for w in $WHAT; do
   case $w in
     tests) (timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x --deselect tests/test_gpu_vae_large.py 2>&1 | tail -40) > $O/pytest_gpu_$TAG.log 2>&1; tail -8 $O/pytest_gpu_$TAG.log;;
+    attnt) (timeout 600 python -m pytest tests/test_gpu_vae.py tests/test_gpu_seqpar.py tests/test_gpu_vae_large.py -m gpu -q --tb=short -p no:cacheprovider -k "attention or attn or seqpar or two_bench" 2>&1 | tail -30) > $O/pytest_attn_$TAG.log 2>&1; tail -12 $O/pytest_attn_$TAG.log;;
     new) (timeout 900 python -m pytest tests/test_gpu_ext.py tests/test_gpu_shard.py -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tail -60) > $O/pytest_new_$TAG.log 2>&1; tail -40 $O/pytest_new_$TAG.log;;
     rec) (timeout 900 python -m pytest tests/test_gpu_rec.py -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tail -60) > $O/pytest_rec_$TAG.log 2>&1; tail -30 $O/pytest_rec_$TAG.log;;
     large) (timeout 600 python -m pytest tests/test_gpu_vae_large.py -m gpu -q --tb=short -p no:cacheprovider -s --durations=10 2>&1 | grep -v "Tiled VAE\|amdgpu.ids" | tail -40) > $O/pytest_large_$TAG.log 2>&1; tail -15 $O/pytest_large_$TAG.log;;
