@@ -188,6 +188,28 @@ int mdtile_noise_inverse_blend(const float* d_noise, const float* d_inverse_nois
 int mdtile_gather_rects(int dtype, int N, int C, int W, int H, const void* d_x_in, const int* rects_xy, int num_rects, int w, int h,
                         int repeat, int tile_major, void* d_out, mdtile_stream_t stream);
 
+/* DemoFusion model evaluation (tile_methods/demofusion.py:219-324).  Tensors NCHW in `dtype`, fp32 accumulation; Hp x Wp is the latent padded
+ * by the jitter range J on every side (forward_one_step, :201-205).
+ *   mdtile_window_blend       local path (:244-257): the T = rows*cols equally sized windows (origins d_window_xy[2 w], [2 w + 1] in the padded
+ *                             canvas, row-major; nominal, un-jittered origins d_nomx[cols] / d_nomy[rows]; every origin lies within
+ *                             [nominal, nominal + 2 J]) are summed in list order and divided by the hit count (0 -> 1).
+ *                             d_tiles [T*N, C, window, window] tile-major (the concatenated model outputs), d_out [N,C,Hp,Wp].
+ *   mdtile_dilated_gather     global path, inputs (:268-283): cell i = (cells_xy[2 i], cells_xy[2 i + 1]) of the S x S lattice ->
+ *                             x[:, :, by+J : Wp-J : S, bx+J : Wp-J : S]; the first num_from_x cells read d_x, the others d_x_filtered (mixture
+ *                             mode); d_out [num_cells*N, C, h0, w0], cells in list order.
+ *   mdtile_demofusion_combine global path, scatter + mix (:284-322): x_global = scatter of d_global_out [cells*N, C, h0, w0] back onto the lattice
+ *                             (mixture: the two copies of a cell are added and halved), out = x_local * (1 - c2) + x_global * c2.
+ *   mdtile_depthwise_blur     Gaussian filter (:173-178): depthwise K x K conv (odd K), zero padding, kernel [K*K] fp32 on the device.
+ *   mdtile_restandardize      (x - st[0]) / st[1] * st[3] + st[2]  with st = { mean, std, target mean, target std } on the device (:264). */
+int mdtile_window_blend(int dtype, const void* d_tiles, void* d_out, const int* d_window_xy, const int* d_nomx, const int* d_nomy, int rows,
+                        int cols, int jitter, int window, int N, int C, int Hp, int Wp, mdtile_stream_t stream);
+int mdtile_dilated_gather(int dtype, const void* d_x, const void* d_x_filtered, int num_from_x, void* d_out, const int* cells_xy, int num_cells,
+                          int N, int C, int Hp, int Wp, int S, int jitter, int h0, int w0, mdtile_stream_t stream);
+int mdtile_demofusion_combine(int dtype, const void* d_x_local, const void* d_global_out, void* d_out, int N, int C, int Hp, int Wp, int S,
+                              int jitter, int h0, int w0, int mixture, float c2, mdtile_stream_t stream);
+int mdtile_depthwise_blur(int dtype, const void* d_x, const float* d_kernel, void* d_out, int planes, int H, int W, int K, mdtile_stream_t stream);
+int mdtile_restandardize(int dtype, const void* d_x, const float* d_stats4, void* d_out, size_t n, mdtile_stream_t stream);
+
 /* ----------------------------------------------------------------------------------------------------------
  * Tiled VAE (scripts/tilevae.py).  All tensors fp32 NCHW.
  * -------------------------------------------------------------------------------------------------------- */

@@ -196,8 +196,10 @@ __global__ __launch_bounds__(512, 2) void k_attn_bf16x3(const u32x4* __restrict_
             asm volatile("" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            // the other stage is free now (slab s-1 / the previous block's P are consumed by every wave): next slab goes out
-            if (s + 1 < NSS) issue_S(kb, s + 1, stage ^ 1);
+            // the other stage is free now (slab s-1 / the previous block's P are consumed by every wave): next slab goes out.
+            // Staggered between the two waves of a SIMD (w, w + 4): waves 0-3 issue their 8 pieces right behind the barrier, waves 4-7
+            // after their first k-step's MFMAs -- one of the pair always feeds the matrix pipe.
+            if (s + 1 < NSS && wave < 4) issue_S(kb, s + 1, stage ^ 1);
             const u32x4* ka = slab + stage * STAGE_REC + (kt_w * KSS * 2) * 64 + lane;
             const u32x4* qa = slab + stage * STAGE_REC + HALF_REC + (2 * qh * KSS * 2) * 64 + lane;
             auto load_ks = [&](int set, int ks) {
@@ -221,6 +223,7 @@ __global__ __launch_bounds__(512, 2) void k_attn_bf16x3(const u32x4* __restrict_
                     for (int j = 0; j < 2; ++j)
                         st[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][term == 0 ? 1 : 0], fb[set][j][term == 1 ? 1 : 0], st[j], 0, 0, 0);
                 MDT_PIN();
+                if (ks == 0 && s + 1 < NSS && wave >= 4) issue_S(kb, s + 1, stage ^ 1);
             }
         }
         // ------------------------------------------------ V^T fragments of the first two 16-key steps go out now (latency under the softmax)
@@ -235,15 +238,18 @@ __global__ __launch_bounds__(512, 2) void k_attn_bf16x3(const u32x4* __restrict_
         load_v(0, 0);
         load_v(1, 1);
         // ------------------------------------------------ online softmax (lane = query column, 16 keys of tile kt_w per j)
+        // (scores are kept in the log2 domain: s' = s * scale * log2(e), so that exp(s - m) = exp2(s' - m') is one v_exp_f32)
         const int key0 = kb * BK + kt_w * 32 + 4 * kg;
+        const float scale2 = scale * 1.4426950408889634f;
+        const bool ragged = (kb + 1) * BK > Tk;          // only the last key block holds padded keys
         float mx[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             float m = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = key0 + (r & 3) + 8 * (r >> 2);
-                const float sv = key < Tk ? st[j][r] * scale : -INFINITY;
+                float sv = st[j][r] * scale2;
+                if (ragged && key0 + (r & 3) + 8 * (r >> 2) >= Tk) sv = -INFINITY;
                 st[j][r] = sv;
                 m = fmaxf(m, sv);
             }
@@ -266,13 +272,13 @@ __global__ __launch_bounds__(512, 2) void k_attn_bf16x3(const u32x4* __restrict_
             const int q = (2 * qh + j) * 32 + l31;
             const float m_blk = fmaxf(fmaxf(smax[q], smax[BQ + q]), fmaxf(smax[2 * BQ + q], smax[3 * BQ + q]));
             const float m_new = fmaxf(m_run[j], m_blk);      // finite: every key block holds >= 1 valid key
-            alpha[j] = expf(m_run[j] - m_new);               // exp(-inf) = 0 on the first block
+            alpha[j] = __builtin_amdgcn_exp2f(m_run[j] - m_new);   // exp2(-inf) = 0 on the first block
             m_run[j] = m_new;
             float ps = 0.0f;
             float pv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                pv[r] = expf(st[j][r] - m_new);              // masked keys: exp(-inf) = 0
+                pv[r] = __builtin_amdgcn_exp2f(st[j][r] - m_new);   // masked keys: exp2(-inf) = 0
                 ps += pv[r];
             }
             ps += __shfl_xor(ps, 32, 64);
@@ -406,7 +412,7 @@ __global__ __launch_bounds__(256) void k_attn_combine(const float* __restrict__ 
     float den = 0.0f;
     for (int s = 0; s < nsplit; ++s) {
         const float* ps = pstat + ((size_t)(s * B + b) * 2) * T128 + q;
-        w[s] = expf(ps[0] - m);
+        w[s] = exp2f(ps[0] - m);                     // the parts' maxima are kept in the log2 domain (see the softmax above)
         den += ps[T128] * w[s];
     }
     const float inv = 1.0f / den;

@@ -81,6 +81,11 @@ _SIGNATURES = {
     "mdtile_halo_exchange": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_int, c_int, c_int, c_int, _IP, POINTER(c_void_p)]),
     "mdtile_allreduce_stats": (c_int, [c_void_p, POINTER(c_void_p), c_int, POINTER(c_void_p)]),
     "mdtile_shard_bcast": (c_int, [c_void_p, POINTER(c_void_p), c_size_t, c_int, POINTER(c_void_p)]),
+    "mdtile_window_blend": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mdtile_dilated_gather": (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, _IP, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mdtile_demofusion_combine": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "mdtile_depthwise_blur": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "mdtile_restandardize": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mdtile_vae_split_tiles": (c_int, [c_int, c_int, c_int, c_int, _IP, _IP, c_int]),
     "mdtile_gn_stats_ws_size": (c_size_t, [c_int, c_int]),
     "mdtile_gn_stats": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -766,6 +771,89 @@ def vae_fast_input(z: torch.Tensor, tile_size: int) -> torch.Tensor:
     out = torch.empty((N, C, oh.value, ow.value), dtype=torch.float32, device=z.device)
     ws = torch.empty((lib().mdtile_vae_fast_ws_size(C) + 7) // 8, dtype=torch.float64, device=z.device)
     _check(lib().mdtile_vae_fast_input(_p(z), N, C, H, W, int(tile_size), _p(out), _p(ws), _stream()), "mdtile_vae_fast_input")
+    return out
+
+
+# ---- DemoFusion (tile_methods/demofusion.py:219-324) -----------------------------------------------------------------------
+class WindowSet:
+    """The jittered local windows of one DemoFusion phase on the device: origins (row-major over rows x cols), their nominal
+    (un-jittered) grid and the jitter range J (every origin lies in [nominal, nominal + 2 J])."""
+
+    def __init__(self, origins: Sequence[Tuple[int, int]], nomx: Sequence[int], nomy: Sequence[int], jitter: int, window: int, device):
+        assert len(origins) == len(nomx) * len(nomy)
+        self.rows, self.cols, self.jitter, self.window = len(nomy), len(nomx), int(jitter), int(window)
+        self.origins = [(int(x), int(y)) for x, y in origins]
+        self.xy = torch.tensor([v for o in self.origins for v in o], dtype=torch.int32, device=device)
+        self.nomx = torch.tensor([int(v) for v in nomx], dtype=torch.int32, device=device)
+        self.nomy = torch.tensor([int(v) for v in nomy], dtype=torch.int32, device=device)
+
+
+def window_blend(tiles: torch.Tensor, ws: WindowSet, N: int, C: int, Hp: int, Wp: int) -> torch.Tensor:
+    """Count-averaged sum of the window outputs (demofusion.py:244-257).  tiles [T*N, C, window, window], tile-major."""
+    _dev_tensor(tiles, "tiles")
+    assert tuple(tiles.shape) == (ws.rows * ws.cols * N, C, ws.window, ws.window)
+    out = torch.empty((N, C, Hp, Wp), dtype=tiles.dtype, device=tiles.device)
+    _check(lib().mdtile_window_blend(dtype_code(tiles.dtype), _p(tiles), _p(out), _p(ws.xy), _p(ws.nomx), _p(ws.nomy), ws.rows, ws.cols, ws.jitter,
+                                     ws.window, N, C, Hp, Wp, _stream()), "mdtile_window_blend")
+    return out
+
+
+def dilated_gather(x: torch.Tensor, x_filtered: Optional[torch.Tensor], num_from_x: int, cells: Sequence[Tuple[int, int]], S: int, jitter: int,
+                   h0: int, w0: int) -> torch.Tensor:
+    """cat([src[:, :, by+J:Wp-J:S, bx+J:Wp-J:S] for (bx, by) in cells]) with src = x for the first num_from_x cells, x_filtered after."""
+    _dev_tensor(x, "x")
+    N, C, Hp, Wp = x.shape
+    if x_filtered is not None:
+        _dev_tensor(x_filtered, "x_filtered", x.dtype)
+        assert x_filtered.shape == x.shape
+    flat = (c_int * (2 * len(cells)))(*[int(v) for c in cells for v in c])
+    out = torch.empty((len(cells) * N, C, h0, w0), dtype=x.dtype, device=x.device)
+    _check(lib().mdtile_dilated_gather(dtype_code(x.dtype), _p(x), _p(x_filtered), int(num_from_x), _p(out), flat, len(cells), N, C, Hp, Wp, int(S),
+                                       int(jitter), int(h0), int(w0), _stream()), "mdtile_dilated_gather")
+    return out
+
+
+def demofusion_combine(x_local: torch.Tensor, global_out: torch.Tensor, S: int, jitter: int, mixture: bool, c2: float) -> torch.Tensor:
+    """x_local * (1 - c2) + scatter(global_out) * c2 (demofusion.py:284-322).  global_out [cells*N, C, h0, w0] in cell-list order."""
+    _dev_tensor(x_local, "x_local")
+    _dev_tensor(global_out, "global_out", x_local.dtype)
+    N, C, Hp, Wp = x_local.shape
+    h0, w0 = global_out.shape[2:]
+    assert global_out.shape[0] == S * S * N * (2 if mixture else 1)
+    out = torch.empty_like(x_local)
+    _check(lib().mdtile_demofusion_combine(dtype_code(x_local.dtype), _p(x_local), _p(global_out), _p(out), N, C, Hp, Wp, int(S), int(jitter), h0, w0,
+                                           int(bool(mixture)), float(c2), _stream()), "mdtile_demofusion_combine")
+    return out
+
+
+def depthwise_blur(x: torch.Tensor, kernel2d: torch.Tensor) -> torch.Tensor:
+    """F.conv2d(x, kernel2d[None, None].repeat(C, 1, 1, 1), padding=K // 2, groups=C)  (demofusion.py:173-178)."""
+    _dev_tensor(x, "x")
+    _dev_tensor(kernel2d, "kernel2d", torch.float32)
+    N, C, H, W = x.shape
+    K = kernel2d.shape[-1]
+    assert tuple(kernel2d.shape) == (K, K) and K % 2 == 1
+    out = torch.empty_like(x)
+    _check(lib().mdtile_depthwise_blur(dtype_code(x.dtype), _p(x), _p(kernel2d), _p(out), N * C, H, W, K, _stream()), "mdtile_depthwise_blur")
+    return out
+
+
+def moments(x: torch.Tensor) -> torch.Tensor:
+    """fp64 [2] = (mean, unbiased std) of the whole tensor, on the device, without a host sync (two-stage fp64 sums of mdtile_gn_sums)."""
+    xf = x if x.dtype == torch.float32 else x.float()
+    n = xf.numel()
+    sums = gn_sums(xf.contiguous().view(1, 1, 1, n), 0, 1, groups=1)[0]          # (sum, sum of squares)
+    mean = sums[0] / n
+    var = (sums[1] - sums[0] * sums[0] / n) / (n - 1)
+    return torch.stack([mean, torch.sqrt(torch.clamp(var, min=0.0))])
+
+
+def restandardize(x: torch.Tensor, stats4: torch.Tensor) -> torch.Tensor:
+    """(x - stats4[0]) / stats4[1] * stats4[3] + stats4[2]; stats4 fp32 [4] on the device."""
+    _dev_tensor(x, "x")
+    _dev_tensor(stats4, "stats4", torch.float32)
+    out = torch.empty_like(x)
+    _check(lib().mdtile_restandardize(dtype_code(x.dtype), _p(x), _p(stats4), _p(out), x.numel(), _stream()), "mdtile_restandardize")
     return out
 
 

@@ -41,6 +41,10 @@ class Method(ComparableEnum):
     MIX_DIFF = "Mixture of Diffusers"
 
 
+class Method_2(ComparableEnum):
+    DEMO_FU = "DemoFusion"
+
+
 class BlendMode(Enum):
     FOREGROUND = "Foreground"
     BACKGROUND = "Background"

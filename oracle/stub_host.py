@@ -141,7 +141,10 @@ def install(device: str | torch.device | None = None) -> types.ModuleType:
         deactivate=lambda p, data: None,
         parse_prompts=lambda prompts: (prompts, {}),
     )
-    _mod("modules.sd_samplers_common", InterruptedException=type("InterruptedException", (BaseException,), {}))
+    _mod("modules.sd_samplers_common", InterruptedException=type("InterruptedException", (BaseException,), {}),
+         Sampler=type("Sampler", (), {"callback_state": lambda self, d: None}),
+         setup_img2img_steps=lambda p, steps=None: (steps or getattr(p, "steps", 20), (steps or getattr(p, "steps", 20)) - 1),
+         store_latent=lambda x: None)
     _mod("modules.images", resize_image=lambda *a, **k: None)
     _mod("modules.sd_samplers", create_sampler=lambda name, model: KDiffusionSampler())
     _mod(
@@ -229,6 +232,11 @@ def load_reference() -> SimpleNamespace:
         absd = importlib.import_module("tile_methods.abstractdiffusion")
         md = importlib.import_module("tile_methods.multidiffusion")
         mod = importlib.import_module("tile_methods.mixtureofdiffusers")
+        try:
+            demofusion = importlib.import_module("tile_methods.demofusion")
+        except Exception as e:                                                   # pragma: no cover
+            demofusion = None
+            print(f"[stub_host] upstream tile_methods/demofusion.py not importable under the stub host: {e!r}")
         tilevae = importlib.import_module("scripts.tilevae")
         try:
             tilediffusion = importlib.import_module("scripts.tilediffusion")   # region-noise hijack (:486-529)
@@ -243,7 +251,9 @@ def load_reference() -> SimpleNamespace:
     # bypass the `shared.sd_model.cond_stage_key` probe (abstractdiffusion.py:17-20)
     md.MultiDiffusion.is_edit_model = False
     mod.MixtureOfDiffusers.is_edit_model = False
-    _REF_CACHE = SimpleNamespace(utils=utils, attn=attn, abstractdiffusion=absd, multidiffusion=md,
+    if demofusion is not None:
+        demofusion.DemoFusion.is_edit_model = False
+    _REF_CACHE = SimpleNamespace(utils=utils, attn=attn, abstractdiffusion=absd, multidiffusion=md, demofusion=demofusion,
                                  mixtureofdiffusers=mod, tilevae=tilevae, tilediffusion=tilediffusion, _modules=ref_mods)
     return _REF_CACHE
 
@@ -259,9 +269,11 @@ def load_plugin() -> SimpleNamespace:
     mod = importlib.import_module("tile_methods.mixtureofdiffusers")
     tilevae = importlib.import_module("scripts.tilevae")
     tilediffusion = importlib.import_module("scripts.tilediffusion")
+    demofusion = importlib.import_module("tile_methods.demofusion")
+    tileglobal = importlib.import_module("scripts.tileglobal")
     engine = importlib.import_module("mdtile")
-    return SimpleNamespace(utils=utils, abstractdiffusion=absd, multidiffusion=md, mixtureofdiffusers=mod,
-                           tilevae=tilevae, tilediffusion=tilediffusion, engine=engine)
+    return SimpleNamespace(utils=utils, abstractdiffusion=absd, multidiffusion=md, mixtureofdiffusers=mod, demofusion=demofusion,
+                           tilevae=tilevae, tilediffusion=tilediffusion, tileglobal=tileglobal, engine=engine)
 
 
 def make_processing(width: int, height: int, sampler_name: str = "Euler", **kw) -> SimpleNamespace:

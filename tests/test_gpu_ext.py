@@ -162,3 +162,95 @@ def test_noise_inversion_sample_img2img_through_the_delegate(plugin, cuda, grid,
     ref = bo.noise_inverse_blend(noise, xt - init_latent / sigmas[0], m, [bo.Region(*r) for r in NI_REGIONS], grid)
     # the bilinear resize of the mask runs on the GPU in the product (host torch op): allow its last-ulp differences
     assert torch.allclose(captured["noise"].cpu(), ref, rtol=1e-5, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# DemoFusion: the delegate's model evaluation on the engine against the oracle (pinned to upstream)
+# ---------------------------------------------------------------------------------------------------------------------
+def _demo_tile_fn(x):
+    return 0.9 * x + 0.1 * x.flip(-1) + 0.05 * x.flip(-2)
+
+
+DEMO_CASES = [  # W0, H0, S, window, overlap, jitter, mixture
+    (24, 24, 2, 16, 8, True, False),
+    (24, 24, 3, 16, 8, True, True),
+    (24, 24, 2, 16, 8, False, False),
+    (20, 20, 2, 16, 4, True, True),
+    (32, 32, 4, 32, 16, True, False),
+]
+
+
+@pytest.mark.parametrize("W0,H0,S,window,overlap,jitter,mixture", DEMO_CASES)
+def test_demofusion_sample_one_step_vs_oracle(plugin, cuda, W0, H0, S, window, overlap, jitter, mixture):
+    import random
+    from oracle import demofusion_oracle as do
+    W, H = W0 * S, H0 * S
+    p = sh.make_processing(W * 8, H * 8)
+    p.random_jitter, p.mixture, p.current_scale_num, p.gaussian_filter = jitter, mixture, S, True
+    p.cosine_scale_2, p.cosine_scale_3 = 1.0, 1.0
+    p.sd_model = SimpleNamespace(apply_model=lambda x, t, cond: _demo_tile_fn(x))
+    smp = sh.kdiff_sampler()
+    smp.model_wrap_cfg = SimpleNamespace(step=0, inner_model=SimpleNamespace(forward=None), image_cfg_scale=None, forward=None)
+    cls = plugin.demofusion.DemoFusion
+    cls.is_edit_model = False
+    d = cls(p, smp)
+    d.window_size, d.sig = window, 0.3
+    d.w, d.h = W, H
+    random.seed(1234)
+    d.get_views(overlap, 3, 2)
+    random.seed(1234)
+    origins, J, _, _ = do.views(W, H, window, overlap, jitter)
+    assert d.jitter_range == J and [(b.x, b.y) for bb in d.batched_bboxes for b in bb] == origins
+    d.sampler_forward = lambda x, sigma, cond: _demo_tile_fn(x)
+    d.cosine_factor = 0.5 * (1 + torch.cos(torch.pi * torch.tensor((3 + 1) / (10 + 1))))
+    torch.manual_seed(3)
+    x = torch.randn(2, 4, H + 2 * J, W + 2 * J)
+    cond = {"c_crossattn": [torch.zeros(2, 77, 8, device=cuda)], "c_concat": [torch.zeros(2, 5, 1, 1, device=cuda)]}
+    got = d.sample_one_step(x.to(cuda), torch.ones(2, device=cuda), cond).cpu()
+    want = do.sample_one_step(x, origins, window, J, 3, 2, S, mixture, True, 0.3, d.cosine_factor, 1.0, 1.0, _demo_tile_fn)
+    # the local path and the scatter / mix are the same fp32 operations in the same order; the Gaussian filter's tap order and the
+    # std reduction differ from torch's (conv2d / std are not order-specified): fp32 round-off only
+    assert torch.allclose(got, want, rtol=2e-5, atol=2e-5), f"max diff {(got - want).abs().max().item()}"
+
+
+def test_demofusion_local_and_scatter_paths_bit_exact(plugin, cuda):
+    """window blend and lattice scatter / mix in isolation: identical to the eager op sequence (fp32, list order)."""
+    import random
+    from oracle import demofusion_oracle as do
+    E = plugin.engine
+    W = H = 48
+    random.seed(7)
+    origins, J, ov, stride = do.views(W, H, 16, 8, True)
+    import math
+    cols = math.ceil((W - ov) / (16 - ov))
+    nom = [min(int(c * ((W - 16) / (cols - 1))), W - 16) for c in range(cols)]
+    N, C, Hp, Wp = 2, 4, H + 2 * J, W + 2 * J
+    torch.manual_seed(2)
+    tiles = torch.randn(len(origins) * N, C, 16, 16)
+    buf, cnt = torch.zeros(N, C, Hp, Wp), torch.zeros(N, C, Hp, Wp)
+    for i, (x, y) in enumerate(origins):
+        buf[:, :, y:y + 16, x:x + 16] += tiles[i * N:(i + 1) * N]
+        cnt[:, :, y:y + 16, x:x + 16] += 1
+    want = buf / torch.where(cnt == 0, torch.tensor(1), cnt)
+    ws = E.WindowSet(origins, nom, nom, J, 16, cuda)
+    got = E.window_blend(tiles.to(cuda), ws, N, C, Hp, Wp).cpu()
+    assert torch.equal(got, want)
+    # lattice gather / scatter + mix
+    S = 3
+    x = torch.randn(N, C, Hp, Wp)
+    xg = torch.randn(N, C, Hp, Wp)
+    end = Wp - J
+    cells = [(bx, by) for by in range(S) for bx in range(S)]
+    h0 = len(range(J, end, S))
+    g = E.dilated_gather(x.to(cuda), xg.to(cuda), 4, cells, S, J, h0, h0).cpu()
+    ref = torch.cat([(x if i < 4 else xg)[:, :, by + J:end:S, bx + J:end:S] for i, (bx, by) in enumerate(cells)], dim=0)
+    assert torch.equal(g, ref)
+    for mixture in (False, True):
+        outs = torch.randn((2 if mixture else 1) * S * S * N, C, h0, h0)
+        xglob = torch.zeros(N, C, Hp, Wp)
+        for i, (bx, by) in enumerate(cells + cells if mixture else cells):
+            xglob[:, :, by + J:end:S, bx + J:end:S] += outs[i * N:(i + 1) * N]
+        c2 = torch.tensor(0.37) ** 1.0
+        want = want * 0 + (buf / torch.where(cnt == 0, torch.tensor(1), cnt)) * (1 - c2) + ((xglob / 2 if mixture else xglob) / 1) * c2
+        got = E.demofusion_combine(E.window_blend(tiles.to(cuda), ws, N, C, Hp, Wp), outs.to(cuda), S, J, mixture, float(c2)).cpu()
+        assert torch.equal(got, want)

@@ -315,3 +315,53 @@ def test_ddim_custom_forward_matches_upstream(ref, lens):
             C.reconstruct_cond, C.reconstruct_uncond = old_rc, old_ru
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert outs[1][0].shape[1] == outs[1][1].shape[1]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# DemoFusion: upstream's delegate (views with jitter, sample_one_step) against oracle/demofusion_oracle.py
+# ---------------------------------------------------------------------------------------------------------------------
+def _demo_tile_fn(x):
+    return 0.9 * x + 0.1 * x.flip(-1) + 0.05 * x.flip(-2)
+
+
+DEMO_CASES = [  # W0, H0 (latent size of the base image), scale S, window, overlap, jitter, mixture, gaussian
+    (24, 24, 2, 16, 8, True, False, True),
+    (24, 24, 3, 16, 8, True, True, True),
+    (24, 24, 2, 16, 8, False, False, True),
+    (20, 20, 2, 16, 4, True, True, True),
+]
+
+
+@pytest.mark.parametrize("W0,H0,S,window,overlap,jitter,mixture,gaussian", DEMO_CASES)
+def test_demofusion_sample_one_step_bit_exact(ref, W0, H0, S, window, overlap, jitter, mixture, gaussian):
+    import random
+    from types import SimpleNamespace
+    from oracle import demofusion_oracle as do
+    if ref.demofusion is None:
+        pytest.skip("upstream demofusion not importable")
+    W, H = W0 * S, H0 * S
+    p = sh.make_processing(W * 8, H * 8)
+    p.random_jitter, p.mixture, p.current_scale_num, p.gaussian_filter = jitter, mixture, S, gaussian
+    p.cosine_scale_2, p.cosine_scale_3 = 1.0, 1.0
+    p.sd_model = SimpleNamespace(apply_model=lambda x, t, cond: _demo_tile_fn(x))
+    smp = sh.kdiff_sampler()
+    smp.model_wrap_cfg = SimpleNamespace(step=0, inner_model=SimpleNamespace(forward=None), image_cfg_scale=None, forward=None)
+    d = ref.demofusion.DemoFusion(p, smp)
+    d.window_size = window
+    d.sig = 0.3
+    d.w, d.h = W, H
+    random.seed(1234)
+    d.get_views(overlap, 3, 2)
+    d.sampler_forward = lambda x, sigma, cond: _demo_tile_fn(x)
+    d.repeat_3 = False
+    d.cosine_factor = 0.5 * (1 + torch.cos(torch.pi * torch.tensor((3 + 1) / (10 + 1))))
+    J = d.jitter_range
+    torch.manual_seed(3)
+    x = torch.randn(2, 4, H + 2 * J, W + 2 * J)
+    cond = {"c_crossattn": [torch.zeros(2, 77, 8)], "c_concat": [torch.zeros(2, 5, 1, 1)]}
+    want = d.sample_one_step(x.clone(), torch.ones(2), cond)
+    random.seed(1234)
+    origins, J2, ov2, stride = do.views(W, H, window, overlap, jitter)
+    assert J2 == J and [(b.x, b.y) for bb in d.batched_bboxes for b in bb] == origins
+    got = do.sample_one_step(x.clone(), origins, window, J, 3, 2, S, mixture, gaussian, 0.3, d.cosine_factor, 1.0, 1.0, _demo_tile_fn)
+    assert torch.equal(got, want)

@@ -123,3 +123,32 @@ def test_tilevae_process_hooks_both_directions_and_restores(plugin):
     assert enc.forward.color_fix and not dec.forward.color_fix          # color_fix is an encoder-only mode (upstream :370)
     s.process(p, False, 3072, 256, True, True, True, False)              # "disabled": undo a hook left over from a crashed job
     assert enc.forward == enc_fwd and dec.forward == dec_fwd
+
+
+def test_demofusion_script_surface(plugin):
+    """scripts/tileglobal.py: title, positional argument order of process (upstream :127-136), delegate method names, hijack restore."""
+    import modules.sd_samplers as sd_samplers
+    import modules.processing as processing
+    s = plugin.tileglobal.Script()
+    assert s.title() == "demofusion"
+    args = list(inspect.signature(plugin.tileglobal.Script.process).parameters)
+    assert args == ["self", "p", "enabled", "method", "keep_input_size", "window_size", "overlap", "tile_batch_size", "scale_factor",
+                    "noise_inverse", "noise_inverse_steps", "noise_inverse_retouch", "noise_inverse_renoise_strength",
+                    "noise_inverse_renoise_kernel", "control_tensor_cpu", "random_jitter", "c1", "c2", "c3", "gaussian_filter",
+                    "strength", "sigma", "batch_size_g", "mixture_mode"]
+    df = plugin.demofusion.DemoFusion
+    for name in ("hook", "unhook", "forward_one_step", "sample_one_step", "get_views", "split_bboxes_jitter", "global_split_bboxes",
+                 "gaussian_kernel", "gaussian_filter", "repeat_tensor", "repeat_cond_dict", "apply_model_hijack", "get_noise"):
+        assert callable(getattr(df, name)), name
+    orig_cs, orig_ci = sd_samplers.create_sampler, getattr(processing, "create_infotext", None)
+    processing.create_infotext = orig_ci or (lambda *a, **k: "")
+    keep = processing.create_infotext
+    p = sh.make_processing(1024, 1024)
+    p.extra_generation_params = {}
+    s.process(p, True, "DemoFusion", False, 64, 32, 4, 2.0, False, 10, 1.0, 1.0, 64, False, True, 3, 1, 1, True, 0.85, 0.6, 4, False)
+    assert sd_samplers.create_sampler is not orig_cs and processing.create_infotext is not keep and callable(p.sample)
+    assert p.extra_generation_params["Tiled Diffusion"]["Method"] == "DemoFusion" and p.scale_factor == 2 and p.mixture is False
+    s.postprocess(p, None, True)
+    assert sd_samplers.create_sampler is orig_cs and processing.create_infotext is keep
+    if orig_ci is None:
+        del processing.create_infotext
