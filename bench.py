@@ -273,7 +273,7 @@ def main():
                 if upsample2x:
                     H, W = 2 * H, 2 * W
                 flops = 2.0 * B * H * W * self.cout * cin * 9
-                tag = "conv3x3_wide"
+                tag = "conv3x3_wide" if self.cout >= 32 else "conv3x3_narrow"
                 if upsample2x:
                     flops *= 4.0 / 9.0
                     tag = "upconv_subpixel"

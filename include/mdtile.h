@@ -278,7 +278,8 @@ int mdtile_conv2d_gn(const float* d_x, const float* d_coef, const float* d_w_pac
  *   mdtile_rec_size            : bytes of the record image of [B, C, H, W]
  *   mdtile_rec_from_f32        : rec = split(silu(a x + s)) (d_coef = mdtile_gn_coeffs output [B][2][C]) or split(x) (d_coef NULL)
  *   mdtile_rec_to_f32          : x = hi + lo (inspection / tests)
- *   mdtile_conv2d_rec_supported: 1 when the record kernels take the shape (3x3, cin % 32 == 0, cout % 128 == 0)
+ *   mdtile_conv2d_rec_supported: 1 when the record kernels take the shape (3x3, cin % 32 == 0, cout % 128 == 0; or cout < 32 -- conv_out:
+ *                                fp32 output only, no residual / upsample, d_bias padded with zeros to 32 floats by the caller)
  *   mdtile_conv2d_rec          : y = conv3x3(x_rec) + bias (+ residual), written as fp32 NCHW (d_y, may be NULL) and / or as the
  *                                record image d_y_rec = split(silu(a y + s)) (d_y_coef [B][2][cout]) or split(y) (d_y_coef NULL);
  *                                MDTILE_CONV_UPSAMPLE2X: x_rec is the HALF-size input of the fused nearest-2x upsample conv

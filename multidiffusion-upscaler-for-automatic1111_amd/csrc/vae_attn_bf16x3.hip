@@ -310,13 +310,24 @@ __global__ __launch_bounds__(512, 2) void k_attn_bf16x3(const u32x4* __restrict_
             l_run[j] = l_run[j] * alpha[j] + ((ssum[q] + ssum[BQ + q]) + (ssum[2 * BQ + q] + ssum[3 * BQ + q]));
         }
         // ------------------------------------------------ output: rescale, then Ot += V^T P^T over the 128 keys (no barrier inside)
+        {
+            // the running maximum of a query settles after a few key blocks: when no query of this wave's tiles moved (alpha == 1
+            // everywhere) the MT_W * NT_W * 16 multiplies are skipped (wave-uniform branch)
+            float an[NT_W];
+            bool moved = false;
 #pragma unroll
-        for (int n = 0; n < NT_W; ++n) {
-            const float a = salpha[(wn * NT_W + n) * 32 + l31];
+            for (int n = 0; n < NT_W; ++n) {
+                an[n] = salpha[(wn * NT_W + n) * 32 + l31];
+                moved = moved || an[n] != 1.0f;
+            }
+            if (__any(moved)) {
 #pragma unroll
-            for (int m = 0; m < MT_W; ++m)
+                for (int n = 0; n < NT_W; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc_o[m][n][r] *= a;
+                    for (int m = 0; m < MT_W; ++m)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc_o[m][n][r] *= an[n];
+            }
         }
         constexpr int HN = NT_W >= 2 ? NT_W / 2 : 1, NH = NT_W / HN;     // query tiles per half-step, half-steps per 16-key step
         bf16x8 fp[2][HN][2];                                              // [set][n][hl]

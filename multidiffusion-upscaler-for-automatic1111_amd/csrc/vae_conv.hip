@@ -232,6 +232,9 @@ int conv_bf16x3_pack(const float* d_w_oihw, void* d_out, int cout, int cin, hipS
 bool conv_bf16x3_gn_supported(int cout, int cin, int ksize, int up);
 int conv_bf16x3_launch(const float* d_x, const void* d_w_rec, const float* d_bias, const float* d_res, float* d_y, int B, int cin,
                        int cout, int H, int W, int up, const float* d_coef, hipStream_t s);
+bool conv_rec_narrow_eligible(int cout, int cin, int ksize);
+size_t conv_rec_narrow_packed_floats(int cin);
+int conv_rec_narrow_pack(const float* d_w_oihw, void* d_out, int cout, int cin, hipStream_t s);
 // vae_conv_rec.hip
 bool conv_rec_supported(int cout, int cin, int ksize);
 size_t rec_image_bytes(int B, int C, int H, int W);
@@ -253,7 +256,8 @@ static size_t f32_packed_floats(int cout, int cin, int ksize) { return ((size_t)
 extern "C" size_t mdtile_conv_packed_size(int cout, int cin, int ksize) {
     if (cout <= 0 || cin <= 0 || (ksize != 1 && ksize != 3)) return 0;
     if (ksize == 1) return f32_packed_floats(cout, cin, ksize) + (conv1x1_bf16x3_eligible(cout, cin) ? conv1x1_bf16x3_packed_floats(cout, cin) : 0);
-    return f32_packed_floats(cout, cin, ksize) + (conv_bf16x3_eligible(cout, cin, ksize) ? conv_bf16x3_packed_floats(cout, cin) : 0);
+    return f32_packed_floats(cout, cin, ksize) + (conv_bf16x3_eligible(cout, cin, ksize) ? conv_bf16x3_packed_floats(cout, cin)
+                                                  : conv_rec_narrow_eligible(cout, cin, ksize) ? conv_rec_narrow_packed_floats(cin) : 0);
 }
 
 extern "C" int mdtile_conv_pack(const float* d_w_oihw, float* d_w_packed, int cout, int cin, int ksize, mdtile_stream_t stream) {
@@ -266,6 +270,8 @@ extern "C" int mdtile_conv_pack(const float* d_w_oihw, float* d_w_packed, int co
         return conv1x1_bf16x3_pack(d_w_oihw, d_w_packed + f32_packed_floats(cout, cin, ksize), cout, cin, as_stream(stream));
     if (conv_bf16x3_eligible(cout, cin, ksize))
         return conv_bf16x3_pack(d_w_oihw, d_w_packed + f32_packed_floats(cout, cin, ksize), cout, cin, as_stream(stream));
+    if (conv_rec_narrow_eligible(cout, cin, ksize))
+        return conv_rec_narrow_pack(d_w_oihw, d_w_packed + f32_packed_floats(cout, cin, ksize), cout, cin, as_stream(stream));
     return MDTILE_OK;
 }
 
@@ -354,8 +360,10 @@ extern "C" int mdtile_conv2d_rec(const void* d_x_rec, const float* d_w_packed, c
     MDT_CHECK_ARG(mdtile_conv2d_rec_supported(cout, cin, 3, flags), "mdtile_conv2d_rec: no record kernel for cout=%d cin=%d flags=%d", cout, cin, flags);
     const int up = (flags & MDTILE_CONV_UPSAMPLE2X) ? 1 : 0;
     MDT_CHECK_ARG(!up || (H % 2 == 0 && W % 2 == 0), "mdtile_conv2d_rec: upsample2x needs even output size, got %dx%d", H, W);
-    MDT_CHECK_ARG(rec_image_ok(B, cin, up ? H / 2 : H, up ? W / 2 : W) && rec_image_ok(B, cout, H, W),
+    MDT_CHECK_ARG(rec_image_ok(B, cin, up ? H / 2 : H, up ? W / 2 : W) && (cout % 32 != 0 || rec_image_ok(B, cout, H, W)),
                   "mdtile_conv2d_rec: unsupported shape B=%d cin=%d cout=%d H=%d W=%d", B, cin, cout, H, W);
+    MDT_CHECK_ARG(cout % 128 == 0 || (!up && !d_y_rec && !d_residual),
+                  "mdtile_conv2d_rec: the narrow (cout < 32) kernel writes fp32 only, no residual, no upsample (cout=%d)", cout);
     return conv_rec_launch(d_x_rec, d_w_packed + f32_packed_floats(cout, cin, 3), d_bias, d_residual, d_y, d_y_rec, d_y_coef, B, cin, cout,
                            H, W, up, as_stream(stream));
 }

@@ -603,6 +603,18 @@ int conv_bf16x3_pack(const float* d_w_oihw, void* d_out, int cout, int cin, hipS
     return MDTILE_OK;
 }
 
+// narrow convs (cout < 32: conv_out) only exist as a record-image kernel (vae_conv_rec.hip, one 32-cout tile per block): their
+// packed image is the direct 3x3 records with MT = 1, NCB = 1, permuted K order
+bool conv_rec_narrow_eligible(int cout, int cin, int ksize) { return ksize == 3 && cin % 32 == 0 && cout >= 1 && cout < 32; }
+size_t conv_rec_narrow_packed_floats(int cin) { return (size_t)(cin / 16) * 3 * 2 * 3 * 1 * 64 * 4; }
+int conv_rec_narrow_pack(const float* d_w_oihw, void* d_out, int cout, int cin, hipStream_t s) {
+    const int NK = cin / 16;
+    const size_t n = (size_t)NK * 3 * 2 * 3 * 64;
+    hipLaunchKernelGGL(k_conv_pack_bf16x3, dim3(cdiv((long long)n, 256)), dim3(256), 0, s, d_w_oihw, (u32x4*)d_out, cout, cin, 1, 1, NK, 1);
+    MDT_LAUNCH_CHECK();
+    return MDTILE_OK;
+}
+
 bool conv_bf16x3_gn_supported(int cout, int cin, int ksize, int up) {
     return conv_bf16x3_eligible(cout, cin, ksize) && !up && cin <= MAX_GN_CIN;
 }

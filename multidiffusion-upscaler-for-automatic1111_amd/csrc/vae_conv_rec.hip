@@ -167,6 +167,7 @@ __device__ __forceinline__ void epilogue_mtile(const EpiCtx& E, const u32x4* ec,
         if (E.y32) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
+                if (cbase + (q & 3) + 8 * (q >> 2) >= E.Cout) continue;          // narrow convs: couts past Cout are padding
                 float* yp = E.y32 + o0 + (size_t)((q & 3) + 8 * (q >> 2)) * E.HW;
                 if (NPX == 2) *reinterpret_cast<float2*>(yp) = make_float2(acc[n][0][q], acc[n][NPX - 1][q]);
                 else *yp = acc[n][0][q];
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rec(const ConvRParams P) {
 
     // epilogue constants of an item's BM couts: waves 0 / 1 / 2 fetch bias / a / s (512 B each; the upper lanes repeat the
     // lower ones into the pad half of the 1 KB slot)
-    const unsigned lane16h = (lane & 31) * 16;
+    const unsigned lane16h = (lane % (MT * 8)) * 16;      // MT * 32 floats = MT * 8 lanes x 16 B; the other lanes repeat them
     auto issue_consts = [&](const WorkItem& it, int par) {
         if (wave == 0 && P.bias) dma16(reinterpret_cast<const char*>(P.bias + it.cb * (MT * 32)), lane16h, ec_l + par * EC_REC);
         if ((wave == 1 || wave == 2) && P.yrec && P.coef)
@@ -460,7 +461,6 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rec(const ConvRParams P) {
         work = work_n;
         cur = nxt;
         par ^= 1;
-#pragma unroll
         for (int i = 0; i < IS::PW; ++i) ioff[i] = ioff_n[i];
     }
 }
@@ -759,7 +759,7 @@ static int num_cus() {
     return n;
 }
 
-bool conv_rec_supported(int cout, int cin, int ksize) { return ksize == 3 && cin % 32 == 0 && cout % 128 == 0; }
+bool conv_rec_supported(int cout, int cin, int ksize) { return ksize == 3 && cin % 32 == 0 && (cout % 128 == 0 || (cout >= 1 && cout < 32)); }
 
 size_t rec_image_bytes(int B, int C, int H, int W) { return (size_t)B * C * (H + 2) * (W + 2) * 4; }
 
@@ -784,7 +784,7 @@ int conv_rec_launch(const void* d_xrec, const void* d_w_rec, const float* d_bias
     P.yrec = (u32x4*)d_yrec; P.coef = d_ycoef;
     P.B = B; P.Cin = cin; P.Cout = cout; P.H = H; P.W = W;
     P.Hin = up ? H / 2 : H; P.Win = up ? W / 2 : W;
-    P.NCB = cout / 128;
+    P.NCB = cout % 128 == 0 ? cout / 128 : 1;
     P.NK = cin / 16;
     if (up) {
         P.w = (const u32x4*)d_w_rec + conv_bf16x3_direct_records(cout, cin);
@@ -802,7 +802,8 @@ int conv_rec_launch(const void* d_xrec, const void* d_w_rec, const float* d_bias
     const long long items = (long long)((P.ptiles + 7) / 8) * 8 * P.NCB * B;
     const int cus = num_cus();                    // one block per CU (155 KB LDS, 2 waves per SIMD)
     dim3 grid((unsigned)((items < cus || !rec_persistent()) ? items : cus / 8 * 8)), block(512);
-    hipLaunchKernelGGL((k_conv3x3_rec<2, 2, 4>), grid, block, 0, s, P);
+    if (cout % 128 == 0) hipLaunchKernelGGL((k_conv3x3_rec<2, 2, 4>), grid, block, 0, s, P);
+    else hipLaunchKernelGGL((k_conv3x3_rec<1, 1, 2>), grid, block, 0, s, P);      // conv_out: one 32-cout tile, bias padded to 32 by the caller
     MDT_LAUNCH_CHECK();
     return MDTILE_OK;
 }

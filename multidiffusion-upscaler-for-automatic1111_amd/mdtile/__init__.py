@@ -652,6 +652,11 @@ class PackedConv:
         self.packed = torch.empty(n, dtype=torch.float32, device=weight.device)
         _check(lib().mdtile_conv_pack(_p(weight), _p(self.packed), self.cout, self.cin, self.ksize, _stream()), "mdtile_conv_pack")
         self.bias = None if bias is None else _dev_tensor(bias.detach().contiguous(), "bias", torch.float32)
+        # the record kernels fetch the bias of a whole 32-cout tile: pad narrow convs (conv_out) with zeros
+        self.bias_rec = self.bias
+        if self.bias is not None and self.cout % 32:
+            self.bias_rec = torch.zeros((self.cout + 31) // 32 * 32, dtype=torch.float32, device=weight.device)
+            self.bias_rec[:self.cout] = self.bias
 
     def down2(self, x: torch.Tensor) -> torch.Tensor:
         """ldm Downsample: conv3x3 stride 2 over pad(x, right 1, bottom 1) (encoder 'downsample' task)."""
@@ -688,7 +693,7 @@ class PackedConv:
         if rec_coef is not None:
             _dev_tensor(rec_coef, "rec_coef", torch.float32)
             assert want_rec and tuple(rec_coef.shape) == (B, 2, self.cout)
-        _check(lib().mdtile_conv2d_rec(_p(x.data), _p(self.packed), _p(self.bias), _p(residual), _p(y), None if yr is None else _p(yr.data),
+        _check(lib().mdtile_conv2d_rec(_p(x.data), _p(self.packed), _p(self.bias_rec), _p(residual), _p(y), None if yr is None else _p(yr.data),
                                        _p(rec_coef), B, self.cin, self.cout, H, W, CONV_UPSAMPLE2X if upsample2x else 0, _stream()),
                "mdtile_conv2d_rec")
         return y, yr

@@ -96,6 +96,24 @@ def test_conv_rec_vs_torch(plugin, cuda, B, cin, cout, H, W, up, res):
     assert _rel(yrec3.to_f32().cpu(), ref) < 1e-4
 
 
+@pytest.mark.parametrize("cin,cout,H,W,B", [(128, 3, 40, 70, 1), (128, 8, 17, 33, 2), (256, 16, 24, 40, 1)])
+def test_conv_rec_narrow_output(plugin, cuda, cin, cout, H, W, B):
+    """conv_out (cout 3 decoder / 8 encoder) on the record path: norm_out + SiLU arrive fused in the record image, one 32-cout tile per
+    block, fp32 output for the real couts only."""
+    E = plugin.engine
+    torch.manual_seed(cin + cout)
+    conv = torch.nn.Conv2d(cin, cout, 3, 1, 1)
+    x = torch.randn(B, cin, H, W)
+    coef = _coef(B, cin, 4)
+    with torch.no_grad():
+        ref = conv(_act(x, coef))
+    pc = E.PackedConv(conv.weight.detach().to(cuda), conv.bias.detach().to(cuda))
+    assert pc.takes_rec()
+    y, yr = pc.call_rec(E.rec_from_f32(x.to(cuda), coef.to(cuda)), want_f32=True)
+    assert yr is None and y.shape == ref.shape
+    assert _rel(y.cpu(), ref) < 1e-4
+
+
 def test_conv_rec_matches_fp32_handover_kernel(plugin, cuda):
     """Same arithmetic contract as the fused-GroupNorm split-bf16 kernel (vae_conv_bf16x3.hip): the two families agree to fp32
     round-off of exp / rcp, far below the split's own 2^-16."""
