@@ -76,3 +76,28 @@ for cin, cout, H, W, up in SHAPES:
         line += f" dev(rec, exact) {((ye - yb).abs().max() / ye.abs().max()).item():.1e}"
     print(line, flush=True)
     del x, res, ya, yb, xrec
+
+if "--fit" in sys.argv:
+    # per-item cost model of the record conv: same image and cout, K depth varied -> time per item = a * NK + b
+    print("per-item model (1112x1112, cout 128, rec->rec): items = pixel tiles (35 x 70 = 2450) x cout blocks", flush=True)
+    pts = []
+    for cin in (128, 256, 512):
+        conv = torch.nn.Conv2d(cin, 128, 3, 1, 1).to(dev)
+        pc = E.PackedConv(conv.weight.detach(), conv.bias.detach())
+        x = torch.randn(1, cin, 1112, 1112, device=dev)
+        ci = torch.stack([torch.rand(1, cin, device=dev) + 0.5, torch.randn(1, cin, device=dev) * 0.3], dim=1).contiguous()
+        co = torch.stack([torch.rand(1, 128, device=dev) + 0.5, torch.randn(1, 128, device=dev) * 0.3], dim=1).contiguous()
+        xrec = E.rec_from_f32(x, ci)
+        res = torch.randn(1, 128, 1112, 1112, device=dev)
+        t_rr = min(timeit(lambda: pc.call_rec(xrec, want_f32=False, want_rec=True, rec_coef=co)) for _ in range(3))
+        t_both = min(timeit(lambda: pc.call_rec(xrec, residual=res, want_f32=True, want_rec=True, rec_coef=co)) for _ in range(3))
+        items = 35 * 70
+        rounds = -(-items // 256)
+        pts.append((cin // 16, t_rr * 1e3 / rounds, t_both * 1e3 / rounds))
+        print(f"  cin {cin:4d} (NK {cin // 16:2d}): rec->rec {t_rr:7.3f} ms = {t_rr * 1e3 / rounds:7.2f} us per item-round | rec->both {t_both:7.3f} ms = {t_both * 1e3 / rounds:7.2f} us", flush=True)
+        del x, xrec, res
+    (n0, a0, b0), (n1, a1, b1), (n2, a2, b2) = pts
+    slope = (a2 - a0) / (n2 - n0)
+    print(f"  fit rec->rec : {slope:6.3f} us per K-step + {a0 - slope * n0:6.2f} us fixed per item   (ideal MFMA time per K-step: 5.76 us @ 2.4 GHz, 7.28 us @ 1.9 GHz)")
+    slope_b = (b2 - b0) / (n2 - n0)
+    print(f"  fit rec->both: {slope_b:6.3f} us per K-step + {b0 - slope_b * n0:6.2f} us fixed per item")
