@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void k_conv(const ConvParams P) {
     const float* xb = P.x + (size_t)b * P.Cin * HWin;
 
     // ---- stage-independent staging maps
-    int goff[NI];  // (kc << 24) | offset inside a channel plane, or -1 (zero padding / outside)
+    int goff[NI];  // offset inside a channel plane, or -1 (zero padding / outside); the channel kc of slot i is (tid + 256 i) / (ROWS TWP)
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int idx = tid + 256 * i;
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void k_conv(const ConvParams P) {
             const int hlim = S == 1 ? P.H : P.Hin, wlim = S == 1 ? P.W : P.Win;   // S = 1: bounds of the (possibly upsampled) input view
             if (gy >= 0 && gy < hlim && gx >= 0 && gx < wlim) {
                 const int sy = P.up ? gy >> 1 : gy, sx = P.up ? gx >> 1 : gx;
-                goff[i] = (kc << 24) | (sy * P.Win + sx);
+                goff[i] = sy * P.Win + sx;
             }
         }
     }
@@ -80,8 +80,8 @@ __global__ __launch_bounds__(256) void k_conv(const ConvParams P) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int g = goff[i];
-            const int kc = g >> 24;
-            rin[i] = (g >= 0 && c0 + kc < P.Cin) ? xb[(size_t)(c0 + kc) * HWin + (g & 0xffffff)] : 0.0f;
+            const int kc = (tid + 256 * i) / (ROWS * TWP);
+            rin[i] = (g >= 0 && c0 + kc < P.Cin) ? xb[(size_t)(c0 + kc) * HWin + g] : 0.0f;
         }
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
@@ -283,7 +283,7 @@ extern "C" int mdtile_conv2d(const float* d_x, const float* d_w_packed, const fl
     MDT_CHECK_ARG(out_layout == 0 || out_layout == 1, "mdtile_conv2d: bad out_layout %d", out_layout);
     const int up = (flags & MDTILE_CONV_UPSAMPLE2X) ? 1 : 0;
     MDT_CHECK_ARG(!up || (H % 2 == 0 && W % 2 == 0), "mdtile_conv2d: upsample2x needs even output size, got %dx%d", H, W);
-    MDT_CHECK_ARG((size_t)(up ? H / 2 : H) * (up ? W / 2 : W) < (1u << 24), "mdtile_conv2d: input plane too large for the staging map");
+    MDT_CHECK_ARG((size_t)(up ? H / 2 : H) * (up ? W / 2 : W) < (1u << 31), "mdtile_conv2d: input plane of 2^31 or more pixels");
     ConvParams P;
     P.x = d_x; P.w = d_w_packed; P.bias = d_bias; P.res = d_residual; P.y = d_y;
     P.B = B; P.Cin = cin; P.Cout = cout; P.CoutP = round_up(cout, 32); P.H = H; P.W = W;
@@ -319,7 +319,7 @@ extern "C" int mdtile_conv2d_gn(const float* d_x, const float* d_coef, const flo
     MDT_CHECK_ARG(B > 0 && B <= 65535 && cin > 0 && cout > 0 && H > 0 && W > 0, "mdtile_conv2d_gn: bad shape B=%d cin=%d cout=%d H=%d W=%d", B, cin, cout, H, W);
     MDT_CHECK_ARG(mdtile_conv2d_gn_supported(cout, cin, ksize, flags, 0),
                   "mdtile_conv2d_gn: no fused pre-activation kernel for cout=%d cin=%d ksize=%d flags=%d (use mdtile_gn_apply + mdtile_conv2d)", cout, cin, ksize, flags);
-    MDT_CHECK_ARG((size_t)H * W < (1u << 24), "mdtile_conv2d_gn: input plane too large for the staging map");
+    MDT_CHECK_ARG((size_t)H * W < (1u << 31), "mdtile_conv2d_gn: input plane of 2^31 or more pixels");
     return conv_bf16x3_launch(d_x, d_w_packed + f32_packed_floats(cout, cin, ksize), d_bias, d_residual, d_y, B, cin, cout, H, W, 0, d_coef,
                               as_stream(stream));
 }
@@ -376,7 +376,7 @@ extern "C" int mdtile_conv2d_down2(const float* d_x, const float* d_w_packed, co
     MDT_CHECK_ARG(d_x && d_w_packed && d_y, "mdtile_conv2d_down2: null argument");
     MDT_CHECK_ARG(B > 0 && B <= 65535 && cin > 0 && cout > 0 && Hin >= 2 && Win >= 2, "mdtile_conv2d_down2: bad shape B=%d cin=%d cout=%d Hin=%d Win=%d",
                   B, cin, cout, Hin, Win);
-    MDT_CHECK_ARG((size_t)Hin * Win < (1u << 24), "mdtile_conv2d_down2: input plane too large for the staging map");
+    MDT_CHECK_ARG((size_t)Hin * Win < (1u << 31), "mdtile_conv2d_down2: input plane of 2^31 or more pixels");
     ConvParams P;
     P.x = d_x; P.w = d_w_packed; P.bias = d_bias; P.res = nullptr; P.y = d_y;
     P.B = B; P.Cin = cin; P.Cout = cout; P.CoutP = round_up(cout, 32);

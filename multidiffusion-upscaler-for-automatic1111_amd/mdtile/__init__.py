@@ -348,6 +348,11 @@ def gather_all(plan: Plan, x_in: torch.Tensor, out: Optional[Sequence[torch.Tens
     _dev_tensor(x_in, "x_in")
     N, C, H, W = x_in.shape
     assert (H, W) == (plan.h, plan.w)
+    if out is None and len(plan.batches) > MAX_BATCHES:
+        # beyond the pointer table of the kernel arguments: one tile-major buffer, the batches are views into it
+        packed = torch.empty((plan.num_tiles * N, C, plan.tile_h, plan.tile_w), dtype=x_in.dtype, device=x_in.device)
+        gather_range(plan, x_in, packed, 0, plan.num_tiles)
+        return list(packed.split([len(b) * N for b in plan.batches], dim=0))
     if out is None:
         out = [torch.empty((len(b) * N, C, plan.tile_h, plan.tile_w), dtype=x_in.dtype, device=x_in.device)
                for b in plan.batches]
@@ -406,6 +411,19 @@ def _regions_array(regions: Sequence[RegionSpec], dtype):
     return arr, keep
 
 
+def _as_one_buffer(parts: Sequence[torch.Tensor]) -> torch.Tensor:
+    """The tensors of `parts` as one contiguous [sum rows, ...] tensor: zero-copy when they are back-to-back views of one storage."""
+    first = parts[0]
+    at, ok = first.data_ptr(), True
+    for t in parts:
+        ok = ok and t.is_contiguous() and t.data_ptr() == at and t.shape[1:] == first.shape[1:] and t.dtype == first.dtype
+        at += t.numel() * t.element_size()
+    rows = sum(t.shape[0] for t in parts)
+    if ok and first.untyped_storage().nbytes() - first.storage_offset() * first.element_size() >= at - first.data_ptr():
+        return first.as_strided((rows,) + tuple(first.shape[1:]), first.stride())
+    return torch.cat(list(parts), dim=0)
+
+
 class BlendCall:
     """A fully marshalled mdtile_blend call: the argument struct, the batch-pointer array and the region array are built ONCE; calling
     the object only does the C call (a few microseconds of host time instead of rebuilding ~10 ctypes objects per evaluation -- the
@@ -424,6 +442,11 @@ class BlendCall:
         assert dtype is not None and device is not None
         for i, t in enumerate(batch_out):
             _dev_tensor(t, f"batch_out[{i}]", dtype)
+        if not packed and len(batch_out) > MAX_BATCHES:
+            # more tile batches than pointers ride in the kernel arguments (e.g. a 1024^2 latent at tile 96 / overlap 48 / batch 1 =
+            # 441): hand the kernel ONE tile-major buffer instead.  Batches are consecutive runs of the tile list, so the views
+            # gather_all returns in this situation are already one buffer; anything else costs one concatenation.
+            batch_out, packed = [_as_one_buffer(batch_out)], True
         flags = (BLEND_PARTIAL if partial else 0) | (BLEND_PACKED if packed else 0) | (BLEND_TILE_RANGE if tile_range is not None else 0)
         if out is None:
             out = torch.empty((N, C, plan.h, plan.w), dtype=torch.float32 if partial else dtype, device=device)

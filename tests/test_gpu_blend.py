@@ -107,6 +107,8 @@ CONFIGS = [  # BASELINE.json configs at full latent size
     ("cfg2", "md", 256, 256, 96, 96, 48, 4), ("cfg3", "mod", 512, 512, 96, 96, 48, 4), ("cfg3b", "mod", 512, 512, 96, 96, 8, 4),
     ("cfg4_md", "md", 1024, 1024, 128, 128, 8, 4), ("cfg4_mod", "mod", 1024, 1024, 128, 128, 8, 4),
     ("cfg4_ov64", "mod", 1024, 1024, 128, 128, 64, 4), ("cfg4_ov64_md", "md", 1024, 1024, 128, 128, 64, 4),
+    # 441 tile batches: more than the 320 pointers that ride in the kernel arguments -> the packed-buffer form behind the same calls
+    ("b441_md", "md", 1024, 1024, 96, 96, 48, 1), ("b441_mod", "mod", 1024, 1024, 96, 96, 48, 1),
 ]
 
 

@@ -136,6 +136,47 @@ def test_conv_at_bench_size(plugin, cuda, cin, cout, H, W, up):
     assert e1 < 1e-4 and e2 < 1e-4, f"conv {cin}->{cout} {H}x{W} up={up}: record kernel {e1}, fp32 hand-over kernel {e2}"
 
 
+def test_convs_on_planes_over_2_pow_24_pixels(plugin, cuda):
+    """The UI's largest tile sizes give planes of more than 2^24 pixels (decoder tile 512 -> 4272^2 in the last level, encoder
+    tile 4096 -> 4160^2 at conv_in): every conv family on such a plane against torch's fp32 conv on the GPU."""
+    E = plugin.engine
+    H, W = 4272, 4160
+    torch.manual_seed(11)
+    x = torch.randn(1, 3, H, W, device=cuda)
+    # exact-fp32 MFMA kernel (conv_in of the encoder: cin 3) and its stride-2 form (Downsample: pad right / bottom)
+    c_in = torch.nn.Conv2d(3, 32, 3, 1, 1).to(cuda)
+    pc_in = E.PackedConv(c_in.weight.detach(), c_in.bias.detach())
+    with torch.no_grad():
+        ref = c_in(x)
+    y = pc_in(x)
+    assert _rel(y, ref) < 1e-5
+    down = torch.nn.Conv2d(32, 32, 3, 2, 0).to(cuda)
+    pc_d = E.PackedConv(down.weight.detach(), down.bias.detach())
+    with torch.no_grad():
+        ref_d = torch.cat([down(F.pad(ref[:, :, r0:r1], (0, 1, 0, 1 if r1 == H else 0)))
+                           for r0, r1 in ((0, H // 2 + 1), (H // 2, H))], dim=2)     # two row bands: torch's im2col index is 32-bit
+    y_d = pc_d.down2(ref)
+    assert y_d.shape == ref_d.shape and _rel(y_d, ref_d) < 1e-4
+    del y_d, ref_d
+    # split-bf16 kernel with the fp32 hand-over (32 -> 32, stride 1, same weights)
+    with torch.no_grad():
+        ref_s = F.conv2d(ref, down.weight, down.bias, 1, 1)
+    assert _rel(pc_d(ref), ref_s) < 1e-4
+    del ref_s
+    # record path: fp32 -> records (+ fused activation), narrow conv_out (32 -> 3), record -> fp32
+    coef = torch.stack([torch.rand(1, 32, device=cuda) + 0.5, torch.randn(1, 32, device=cuda) * 0.3], dim=1).contiguous()
+    rec = E.rec_from_f32(ref, coef)
+    act = F.silu(ref * coef[:, 0].view(1, 32, 1, 1) + coef[:, 1].view(1, 32, 1, 1))
+    assert _rel(rec.to_f32(), act) < 2e-5
+    c_out = torch.nn.Conv2d(32, 3, 3, 1, 1).to(cuda)
+    pc_out = E.PackedConv(c_out.weight.detach(), c_out.bias.detach())
+    assert pc_out.takes_rec()
+    with torch.no_grad():
+        ref_o = c_out(act)
+    y_o, _ = pc_out.call_rec(rec, want_f32=True)
+    assert _rel(y_o, ref_o) < 1e-4
+
+
 def test_decode_two_bench_tiles_vs_oracle_on_gpu(plugin, cuda):
     """Latent 278 x 512 at decoder tile 256 -> two tiles, 278x278 and 278x256 (the two tile shapes of the 8K decode; T = 77 284
     and 71 168 tokens; convs up to 2224x2224), fast mode: default (split-bf16, record path) and strict-fp32 engine vs the
