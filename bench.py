@@ -328,8 +328,8 @@ def main():
     if rank == 0 and pmc_path and os.path.exists(pmc_path):
         with open(pmc_path) as f:
             pmc = json.load(f)
-        for rl, needle in ((roofline, {"conv3x3_wide": "k_conv3x3_bf16x3", "attn": "k_attn_bf16x3", "upconv_subpixel": "k_upconv_bf16x3"}.get(
-                (roofline or {}).get("kernel", ""), "")), (roofline_blend, "k_blend")):
+        for rl, needle in ((roofline, {"conv3x3_wide": "k_conv3x3_rec<2, 2, 4>", "attn": "k_attn_bf16x3", "upconv_subpixel": "k_upconv_rec"}.get(
+                (roofline or {}).get("kernel", ""), "")), (roofline_blend, "k_blend<")):
             if rl is not None and needle:
                 hit = [v for k, v in pmc.get("kernels", {}).items() if needle in k]
                 if hit:
