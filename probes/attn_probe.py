@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.join(ROOT, "multidiffusion-upscaler-for-automatic1111
 import mdtile as E
 
 dev = torch.device("cuda:0")
+ZEROS = "--zeros" in sys.argv     # all-zero q / k / v: same instruction stream, no operand toggling (DVFS / power check)
 QUICK = "--quick" in sys.argv     # one mid-size problem, split-bf16 kernel only (counter passes)
 Ts = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or ([30000] if QUICK else [7396, 30000, 71168, 77284])
 C = 512
@@ -13,6 +14,8 @@ for T in Ts:
     torch.manual_seed(0)
     q, k = torch.randn(1, C, T, device=dev), torch.randn(1, C, T, device=dev)
     v = torch.randn(1, T, C, device=dev)
+    if ZEROS:
+        q.zero_(), k.zero_(), v.zero_()
     scale = C ** -0.5
     flops = 4.0 * T * T * C
     line = f"T={T:6d} C={C}: "

@@ -24,6 +24,7 @@ SHAPES = [  # cin, cout, H, W, upsample
 if "--shapes" in sys.argv:
     SHAPES = [SHAPES[int(i)] for i in sys.argv[sys.argv.index("--shapes") + 1].split(",")]
 EXACT = "--exact" in sys.argv
+ZEROS = "--zeros" in sys.argv      # all-zero activations AND weights: same instruction stream, no operand toggling (DVFS / power check)
 
 
 def timeit(fn, n=6):
@@ -41,11 +42,18 @@ def timeit(fn, n=6):
 torch.manual_seed(0)
 for cin, cout, H, W, up in SHAPES:
     conv = torch.nn.Conv2d(cin, cout, 3, 1, 1).to(dev)
+    if ZEROS:
+        with torch.no_grad():
+            conv.weight.zero_()
     pc = E.PackedConv(conv.weight.detach(), conv.bias.detach())
     hin, win = (H // 2, W // 2) if up else (H, W)
     x = torch.randn(1, cin, hin, win, device=dev)
+    if ZEROS:
+        x.zero_()
     res = torch.randn(1, cout, H, W, device=dev)
     coef_in = torch.stack([torch.rand(1, cin, device=dev) + 0.5, torch.randn(1, cin, device=dev) * 0.3], dim=1).contiguous()
+    if ZEROS:
+        coef_in.zero_()         # silu(0 x + 0) = 0: the staged operands are exact zeros too
     coef_out = torch.stack([torch.rand(1, cout, device=dev) + 0.5, torch.randn(1, cout, device=dev) * 0.3], dim=1).contiguous()
     flops = 2.0 * H * W * cout * cin * 9
     line = f"{cin:4d}->{cout:4d} {H}x{W}{' up' if up else '   '}: "
