@@ -73,6 +73,7 @@ class Profile:
 
     def __init__(self):
         self.records = []   # (tag, work, start_event, end_event)
+        self.extra = []     # (tag, n, work, seconds) measured elsewhere
 
     def wrap(self, tag, work, fn):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -82,9 +83,17 @@ class Profile:
         self.records.append((tag, work, s, e))
         return out
 
+    def add(self, tag, n, work, secs):
+        self.extra.append((tag, n, work, secs))
+
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
+        for tag, n, work, secs in self.extra:
+            a = agg.setdefault(tag, [0, 0.0, 0.0])
+            a[0] += n
+            a[1] += work
+            a[2] += secs
         for tag, work, s, e in self.records:
             a = agg.setdefault(tag, [0, 0.0, 0.0])
             a[0] += 1
@@ -250,7 +259,15 @@ def main():
                     blend_call()
             for _ in range(3):
                 blend_call()
-            prof.wrap("blend", 20 * blend_bytes, _twenty)
+            # five rounds of 20; the median round is reported (the first round after the decode still pulls the tiles from HBM
+            # into the Infinity Cache and runs at the clock the idle gap left)
+            rounds = []
+            for _ in range(5):
+                p1 = Profile()
+                p1.wrap("blend", 20 * blend_bytes, _twenty)
+                rounds.append(p1.summary()["blend"])
+            rounds.sort(key=lambda r: r[2])
+            prof.add("blend", *rounds[2])
         if hook is not None:
             orig_call = E.PackedConv.__call__
             orig_rec = E.PackedConv.call_rec
@@ -303,7 +320,8 @@ def main():
             ach = work / secs / 1e9
             roofline_blend = {"kernel": "k_blend", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "launches": n,
-                              "avg_us": round(secs / n * 1e6, 2), "bytes_per_launch": int(work / n)}
+                              "avg_us": round(secs / n * 1e6, 2), "bytes_per_launch": int(work / n),
+                              "timing": "median of 5 rounds of 20 back-to-back launches between one pair of HIP events"}
         conv_tags = {k: v for k, v in agg.items() if k.startswith("conv") or k.startswith("upconv") or k == "attn"}
         if conv_tags:
             dom = max(conv_tags, key=lambda k_: conv_tags[k_][2])

@@ -298,8 +298,18 @@ __global__ __launch_bounds__(256) void k_blend(const BlendParams P) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (wq[j] > 1.0f) {   // correctly rounded division, only where upstream divides
+                const unsigned wb = __float_as_uint(wq[j]);
+                if ((wb & 0x007fffffu) == 0u) {
+                    // w = 2^k (every overlap count of a plain grid: 2, 4): x / w == x * 2^-k bit for bit (both are the correctly
+                    // rounded value of the same exact quotient), and 2^-k is exponent arithmetic -- the 10-instruction IEEE
+                    // division sequence x 32 values per thread sat between the last load and the first store of every wave
+                    const float r = __uint_as_float(0x7f000000u - wb);
 #pragma unroll
-                for (int pp = 0; pp < PP; ++pp) acc[pp][j] = acc[pp][j] / wq[j];
+                    for (int pp = 0; pp < PP; ++pp) acc[pp][j] = acc[pp][j] * r;
+                } else {
+#pragma unroll
+                    for (int pp = 0; pp < PP; ++pp) acc[pp][j] = acc[pp][j] / wq[j];
+                }
             }
         }
     }

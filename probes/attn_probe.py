@@ -38,3 +38,24 @@ for T in Ts:
     if len(outs) == 2:
         line += f"max dev {((outs[False] - outs[True]).abs().max() / outs[True].abs().max()).item():.2e}"
     print(line, flush=True)
+
+
+if "--ab-zeros" in sys.argv:
+    # same process, alternating random / all-zero q, k, v (identical instruction stream): how much of the time is the clock
+    T = Ts[-1]
+    torch.manual_seed(1)
+    qr, kr, vr = torch.randn(1, C, T, device=dev), torch.randn(1, C, T, device=dev), torch.randn(1, T, C, device=dev)
+    qz, kz, vz = torch.zeros_like(qr), torch.zeros_like(kr), torch.zeros_like(vr)
+    flops = 4.0 * T * T * C
+    for rep in range(3):
+        for name, (a, b, c) in (("random", (qr, kr, vr)), ("zeros ", (qz, kz, vz))):
+            E.vae_attn(a, b, c, C ** -0.5)
+            torch.cuda.synchronize()
+            s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_.record()
+            for _ in range(4):
+                E.vae_attn(a, b, c, C ** -0.5)
+            e_.record()
+            torch.cuda.synchronize()
+            ms = s_.elapsed_time(e_) / 4
+            print(f"  T={T} {name}: {ms:8.3f} ms {flops / ms * 1e-9:7.1f} TF", flush=True)
