@@ -12,7 +12,7 @@ packed = torch.randn(T * N, C, th, tw, device=dev)
 weights = torch.zeros(H, W, device=dev)
 E.weight_map_add_grid(plan, None, weights)
 out = torch.empty(N, C, H, W, device=dev)
-def run(tag):
+def run(tag, n=50):
     call = E.BlendCall(plan, E.METHOD_MD, [packed], N, C, weights=weights, out=out, packed=True)
     for _ in range(5): call()
     torch.cuda.synchronize()
@@ -20,10 +20,16 @@ def run(tag):
     for rep in range(5):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        for _ in range(50): call()
+        for _ in range(n): call()
         e.record(); torch.cuda.synchronize()
-        best = min(best, s.elapsed_time(e) / 50 * 1e3)
+        best = min(best, s.elapsed_time(e) / n * 1e3)
     print(f"{tag}: {best:.2f} us  {80216064 / best * 1e-3:.0f} GB/s", flush=True)
+os.environ["MDTILE_BLEND_CFG"] = "0,0"
+for n in (1, 5, 20, 50, 200):
+    run(f"default cfg, {n:3d} launches per event pair", n)
+if "--data" in sys.argv:
+    # operand dependence (the HBM path has a data-dependent cost too?): zeros / random tiles
+    packed.zero_(); run("zero tiles, 50 launches"); packed.normal_(); run("random tiles, 50 launches")
 for cfg in ("0,0", "8,2", "8,4", "4,2", "4,4", "2,4"):
     os.environ["MDTILE_BLEND_CFG"] = cfg
     run(f"cfg {cfg}")
