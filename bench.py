@@ -137,7 +137,7 @@ def main():
     if world > 1 and not args.debug_single_device and os.environ.get("MDTILE_SHARD_TORCH", "") != "1":
         # halo exchange through the C ABI (mdtile_shard_init_rank + mdtile_halo_exchange: pack, ncclSend / ncclRecv over xGMI,
         # fixed-order k_halo_add) instead of torch.distributed point-to-point + eager slab arithmetic
-        sharding.init_process_context(rank, world, local_rank)
+        sharding.init_process_context_checked(rank, world, local_rank)     # falls back to torch.distributed on every rank if any rank fails
     from oracle import ldm_decoder as ld  # only for the random-weight SD-shaped decoder definition
 
     L, N, C = args.latent, 2, 4

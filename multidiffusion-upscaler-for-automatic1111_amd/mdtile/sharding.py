@@ -163,6 +163,58 @@ def init_process_context(rank: int, world: int, device: int, group=None):
     return _CTX
 
 
+def init_process_context_checked(rank: int, world: int, device: int, timeout_s: float = 120.0, group=None) -> bool:
+    """init_process_context with a seat belt for its first contact with a given node: the communicator is created in a worker
+    thread (a rendezvous that never completes must not hang the job), then a small halo exchange through the C ABI is compared
+    with the same exchange over torch.distributed point-to-point.  Every rank reports; unless ALL succeeded the context is
+    dropped everywhere and exchange_and_sum keeps using torch.distributed.  Returns whether the C-ABI path is active."""
+    global _CTX
+    import sys
+    import threading
+    err: List[BaseException] = []
+
+    def _init():
+        try:
+            init_process_context(rank, world, device, group)
+        except BaseException as e:     # noqa: BLE001 -- reported below, the job continues on the torch.distributed path
+            err.append(e)
+
+    t = threading.Thread(target=_init, daemon=True)
+    t.start()
+    t.join(timeout_s)
+    ok = not t.is_alive() and not err and _CTX is not None
+    why = "timed out" if t.is_alive() else (repr(err[0]) if err else "")
+    dev = torch.device("cuda", device)
+    if ok:
+        try:
+            rows = 8 * world
+            bands = [Band(r, r, r + 1, r, r + 1, max(0, 8 * r - 2), min(rows, 8 * r + 10), 8 * r, 8 * r + 8) for r in range(world)]
+            g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+            a = torch.randn(2, 4, rows, 64, generator=g).to(dev)
+            b = a.clone()
+            exchange_and_sum_ctx(a, bands)
+            ctx, _CTX = _CTX, None
+            try:
+                exchange_and_sum(b, bands, rank, group)
+            finally:
+                _CTX = ctx
+            lo, hi = bands[rank].row_lo, bands[rank].row_hi
+            torch.cuda.synchronize(dev)
+            if not torch.equal(a[:, :, lo:hi], b[:, :, lo:hi]):
+                ok, why = False, "halo self-check mismatch against torch.distributed"
+        except BaseException as e:     # noqa: BLE001
+            ok, why = False, repr(e)
+    flag = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if not ok:
+        print(f"[mdtile] rank {rank}: C-ABI shard context unavailable ({why}); halo exchange stays on torch.distributed", file=sys.stderr)
+    if int(flag.item()) == 0:
+        _CTX = None
+        _CTX_SCRATCH.clear()
+        return False
+    return True
+
+
 def band_rows_table(bands: Sequence[Band]) -> List[int]:
     out = []
     for b in bands:

@@ -98,3 +98,67 @@ def test_vae_multi_device_sweep_matches_single_device(plugin, cuda):
     hook.devices = [0, 0, 0]
     many = hook(z)
     assert many.device == one.device and torch.equal(many, one)
+
+
+# ---- process-per-GPU bring-up with the seat belt (bench.py at N > 1) -------------------------------------------------------
+def _free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _ctx_worker(rank, world, port, q):
+    import os
+    import sys
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "multidiffusion-upscaler-for-automatic1111_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from mdtile import sharding
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        active = sharding.init_process_context_checked(rank, world, 0, timeout_s=60.0)
+        # whichever transport survived, the exchange must give the rank-ordered sum on this band's rows
+        rows = 8 * world
+        bands = [sharding.Band(r, r, r + 1, r, r + 1, max(0, 8 * r - 3), min(rows, 8 * r + 11), 8 * r, 8 * r + 8) for r in range(world)]
+        parts = [torch.randn(2, 4, rows, 32, generator=torch.Generator().manual_seed(50 + r)) for r in range(world)]
+        mine = parts[rank].to(dev)
+        sharding.exchange_and_sum(mine, bands, rank)
+        lo, hi = bands[rank].row_lo, bands[rank].row_hi
+        want = torch.zeros(2, 4, rows, 32)
+        for r in range(world):                              # ascending rank order, contributors only
+            b = bands[r]
+            a, e = max(lo, b.row_lo), min(hi, b.row_hi)
+            if a < e:
+                want[:, :, a:e] += parts[r][:, :, a:e]
+        ok = torch.equal(mine.cpu()[:, :, lo:hi], want[:, :, lo:hi])
+        q.put((rank, bool(active), ok, ""))
+        dist.destroy_process_group()
+    except BaseException as e:  # noqa: BLE001
+        q.put((rank, None, False, repr(e)))
+
+
+def test_process_context_bringup_agrees_and_exchanges(plugin, cuda):
+    """Two processes on cuda:0 (gloo rendezvous): RCCL cannot put two ranks on one device, so the checked bring-up must end
+    in the SAME state on both ranks -- normally 'fall back to torch.distributed' -- and the exchange must still be exact."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ctx_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert all(r[3] == "" for r in res), res
+    assert res[0][1] == res[1][1], f"ranks disagree about the transport: {res}"
+    assert all(r[2] for r in res), res
