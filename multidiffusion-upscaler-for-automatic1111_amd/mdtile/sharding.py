@@ -175,6 +175,8 @@ def init_process_context_checked(rank: int, world: int, device: int, timeout_s: 
 
     def _init():
         try:
+            if torch.cuda.is_available():
+                torch.cuda.set_device(device)      # the current device is per thread; the id broadcast below runs on it
             init_process_context(rank, world, device, group)
         except BaseException as e:     # noqa: BLE001 -- reported below, the job continues on the torch.distributed path
             err.append(e)
