@@ -21,7 +21,6 @@
 
 using namespace mdt;
 
-#define MDT_DEBUG_SKIP_NORM 0x100  // probing only: MultiDiffusion without the weights>1 division
 
 namespace {
 
@@ -294,7 +293,7 @@ __global__ __launch_bounds__(256) void k_blend(const BlendParams P) {
     }
 
     // MD normalisation: x = where(weights > 1, buf / weights, buf)  (multidiffusion.py:208); the weight is per pixel, shared by planes
-    if (METHOD == MDTILE_METHOD_MD && !(P.flags & MDT_DEBUG_SKIP_NORM)) {
+    if (METHOD == MDTILE_METHOD_MD) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (wq[j] > 1.0f) {   // correctly rounded division, only where upstream divides
