@@ -337,6 +337,11 @@ def main():
                         "avg_us": round(secs / n * 1e6, 1), "flops_per_launch": work / n,
                         "breakdown_s": {k: round(v[2], 4) for k, v in sorted(agg.items())},
                         "breakdown_tflops": {k: round(v[1] / v[2] / 1e12, 2) for k, v in sorted(conv_tags.items())}}
+            if bf16x3:
+                # measured once, not in this run: see DESIGN.md section 3 and the named log
+                roofline["clock_note"] = ("peak is quoted at 2.4 GHz; under this kernel's load the chip's power management runs ~1.8-1.9 GHz "
+                                          "(same binary and launch on all-zero operands: 669 TFLOP/s = 0.80 of peak against 486 on random data, "
+                                          "profiles/r2o/conv_probe_random_vs_zero_operands.log)")
         elif roofline_blend is not None:
             roofline = roofline_blend
 
