@@ -2,8 +2,11 @@
 """Per-kernel averages of SQ / GRBM counters from one or more rocprofv3 --pmc passes.   usage: pmc_sq.py <out.json> <dir> [<dir> ...]
 SQ_* are quad-cycles summed over waves except SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over SIMDs): for a 32x32x16 bf16 MFMA it
 is 32 x the MFMAs issued.  Derived: MFMA-pipe busy fraction = BUSY_CYCLES / (4 SIMDs x 256 CUs x kernel time x clock), with the
-clock taken both at the nominal 2.4 GHz and from GRBM_GUI_ACTIVE / kernel time when that counter was collected."""
+clock taken both at the nominal 2.4 GHz and from GRBM_GUI_ACTIVE / kernel time when that counter was collected (rocprofv3 reports
+GRBM_GUI_ACTIVE summed over the 8 XCDs: divided by XCDS here)."""
 import collections, csv, glob, gzip, json, os, sys
+
+XCDS = 8
 
 
 def main():
@@ -32,9 +35,9 @@ def main():
             if "SQ_VALU_MFMA_BUSY_CYCLES" in e:
                 e["mfma_busy_frac_at_2.4GHz"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * e["avg_ns"] * 2.4)
             if "GRBM_GUI_ACTIVE" in e:
-                e["clock_GHz"] = e["GRBM_GUI_ACTIVE"] / e["avg_ns"]
+                e["clock_GHz"] = e["GRBM_GUI_ACTIVE"] / XCDS / e["avg_ns"]
                 if "SQ_VALU_MFMA_BUSY_CYCLES" in e:
-                    e["mfma_busy_frac_at_clock"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * e["GRBM_GUI_ACTIVE"])
+                    e["mfma_busy_frac_at_clock"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * e["GRBM_GUI_ACTIVE"] / XCDS)
         if "SQ_WAVE_CYCLES" in e:
             for nm, c in (("wave_parked_frac", "SQ_WAIT_ANY"), ("wave_issue_stall_frac", "SQ_WAIT_INST_ANY"), ("wave_issuing_frac", "SQ_ACTIVE_INST_ANY")):
                 if c in e:
