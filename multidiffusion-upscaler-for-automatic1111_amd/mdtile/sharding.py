@@ -186,7 +186,7 @@ def init_process_context_checked(rank: int, world: int, device: int, timeout_s: 
     t.join(timeout_s)
     ok = not t.is_alive() and not err and _CTX is not None
     why = "timed out" if t.is_alive() else (repr(err[0]) if err else "")
-    dev = torch.device("cuda", device)
+    dev = torch.device("cuda", device) if torch.cuda.is_available() else torch.device("cpu")   # (cpu: the gloo tests of this logic)
     if ok:
         try:
             rows = 8 * world
@@ -201,7 +201,8 @@ def init_process_context_checked(rank: int, world: int, device: int, timeout_s: 
             finally:
                 _CTX = ctx
             lo, hi = bands[rank].row_lo, bands[rank].row_hi
-            torch.cuda.synchronize(dev)
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
             if not torch.equal(a[:, :, lo:hi], b[:, :, lo:hi]):
                 ok, why = False, "halo self-check mismatch against torch.distributed"
         except BaseException as e:     # noqa: BLE001

@@ -150,3 +150,37 @@ def test_sharded_blend_halo_exchange(world, method, W, H, tw, th, ov):
 
 def test_slow_mode_stats_allreduce():
     _run(_worker_stats, 2)
+
+
+def _worker_bringup(rank, world, port, q):
+    """No GPU here: the C-ABI context cannot come up, so the checked bring-up must report 'inactive' on EVERY rank (the vote)
+    and leave exchange_and_sum on the torch.distributed path, still exact."""
+    try:
+        _setup(rank, world, port)
+        from mdtile import sharding
+        active = sharding.init_process_context_checked(rank, world, 0, timeout_s=30.0)
+        assert active is False and sharding._CTX is None
+        rows = 8 * world
+        bands = [sharding.Band(r, r, r + 1, r, r + 1, max(0, 8 * r - 3), min(rows, 8 * r + 11), 8 * r, 8 * r + 8) for r in range(world)]
+        parts = [torch.randn(2, 4, rows, 16, generator=torch.Generator().manual_seed(90 + r)) for r in range(world)]
+        mine = parts[rank].clone()
+        sharding.exchange_and_sum(mine, bands, rank)
+        lo, hi = bands[rank].row_lo, bands[rank].row_hi
+        want = torch.zeros_like(mine)
+        for r in range(world):
+            a, e = max(lo, bands[r].row_lo), min(hi, bands[r].row_hi)
+            if a < e:
+                want[:, :, a:e] += parts[r][:, :, a:e]
+        assert torch.equal(mine[:, :, lo:hi], want[:, :, lo:hi])
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_checked_bringup_votes_and_falls_back(world):
+    _run(_worker_bringup, world)
