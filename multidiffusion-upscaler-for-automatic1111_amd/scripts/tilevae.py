@@ -19,7 +19,7 @@ upstream :492-496).
 from __future__ import annotations
 
 from time import time
-from typing import List, Optional, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import torch
 from torch import Tensor
@@ -37,6 +37,7 @@ import os as _os
 FUSE_PRE_GN = _os.environ.get("MDTILE_FUSE_GN", "1") != "0"
 # fast mode with every norm frozen: activations travel between the 3x3 convs as split-bf16 record images that the PRODUCING
 # conv writes already normalised + SiLU'd (engine: mdtile_conv2d_rec); MDTILE_REC=0 keeps the fp32 hand-over (A/B, debugging)
+TILE_BATCH = int(_os.environ.get("MDTILE_TILE_BATCH", "3"))     # fast mode: tiles of equal shape per sweep (see vae_tile_forward)
 REC_PATH = _os.environ.get("MDTILE_REC", "1") != "0"
 # multi-GPU fast mode: run the GroupNorm estimator sequence-parallel across the ranks (mdtile/seqpar.py); 0 = every rank
 # repeats the whole estimator (no communication, but 1 of every rank's ~3 work units at 8 GPUs)
@@ -524,6 +525,36 @@ class VAEHook:
                 norm_ord = {i: k for k, i in enumerate(i for i, s in enumerate(steps) if s.kind == "norm")}
                 coefs = [E.gn_coeffs(mean, var, steps[i].norm[0], steps[i].norm[1], steps[i].channels, 32, 1e-6)
                          for i, (var, mean) in zip(norm_ord, frozen)]
+            if use_rec and TILE_BATCH > 1:
+                # Tiles of one shape go through the sweep TOGETHER (stacked along the batch axis, TILE_BATCH at a time).  Upstream
+                # walks them one by one (:578-642); with frozen statistics they are independent, so the result is the same -- but
+                # a conv launch over one tile fills the 256 CUs in ceil(items / 256) rounds and the last round is mostly empty
+                # (256 -> 256 at 1112^2: 4 900 items = 19.1 rounds, 4 % idle; 512 -> 512 at 278^2: 2.5 rounds, 16 % idle).
+                # 288 GB of HBM hold several tiles' activations at once (3 tiles of 278^2: ~40 GB).
+                groups: Dict[Tuple[int, int], List[int]] = {}
+                for i in mine:
+                    groups.setdefault(tuple(tiles[i].x.shape[2:]), []).append(i)
+                for shape_key in sorted(groups, key=lambda kk: -len(groups[kk])):
+                    ids = groups[shape_key]
+                    for c0 in range(0, len(ids), TILE_BATCH):
+                        if state.interrupted:
+                            interrupted = True
+                            break
+                        chunk = ids[c0:c0 + TILE_BATCH]
+                        T = len(chunk)
+                        xb = tiles[chunk[0]].x if T == 1 else torch.cat([tiles[i].x for i in chunk], dim=0)
+                        fz = frozen if T == 1 else [(v.repeat(T), m.repeat(T)) for v, m in frozen]
+                        cf = coefs if T == 1 else [c.repeat(T, 1, 1) for c in coefs]
+                        for i in chunk:
+                            tiles[i].x = None
+                        yb = self._run_tile_rec(steps, xb, fz, cf, norm_ord)
+                        for t, i in enumerate(chunk):
+                            tiles[i].x = yb[t * N:(t + 1) * N]
+                            finish(i)
+                        del xb, yb
+                    if interrupted:
+                        break
+                mine = []        # all done (or interrupted)
             for i in mine:
                 if state.interrupted:
                     interrupted = True
