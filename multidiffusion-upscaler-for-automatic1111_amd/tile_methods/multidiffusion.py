@@ -70,7 +70,11 @@ class MultiDiffusion(AbstractDiffusion):
             return self.sampler_forward(x_tile, self.repeat_tensor(ts_in, n), cond=cond_tile)
 
         def custom_func(x, bbox_id, bbox):
-            return self.ddim_custom_forward(x, cond, bbox, ts_in, self.sampler_forward)
+            def forward_func(x, *args, **kwargs):          # the region's control tensors are set right before its model call (:92-95)
+                self.set_custom_controlnet_tensors(bbox_id, 2 * x.shape[0])
+                self.set_custom_stablesr_tensors(bbox_id)
+                return self.sampler_forward(x, *args, **kwargs)
+            return self.ddim_custom_forward(x, cond, bbox, ts_in, forward_func)
 
         return self.sample_one_step(x_in, org_func, repeat_func, custom_func)
 

@@ -166,14 +166,16 @@ class BlendOracle:
     def gather(self, x_in: torch.Tensor, batch) -> torch.Tensor:
         return torch.cat([x_in[:, :, y:y + th, x:x + tw] for (x, y, tw, th) in batch], dim=0)
 
-    def evaluate(self, x_in: torch.Tensor, tile_fn: Denoiser, region_fn: Optional[Callable] = None) -> torch.Tensor:
+    def evaluate(self, x_in: torch.Tensor, tile_fn: Denoiser, region_fn: Optional[Callable] = None, with_boxes: bool = False) -> torch.Tensor:
         """One hijacked forward.  `tile_fn(x_tile[bs*N,C,th,tw])` stands in for the UNet on a tile batch;
-        `region_fn(x_region, idx)` for the per-region custom forward."""
+        `region_fn(x_region, idx)` for the per-region custom forward.  with_boxes: the callbacks also receive the batch's
+        bbox list / the Region (what upstream's repeat_func / custom_func get, multidiffusion.py:163,184) -- used by
+        oracle/entry_oracle.py, whose stand-in model depends on per-tile conditioning."""
         N = x_in.shape[0]
         buf = torch.zeros_like(x_in)                                              # abstractdiffusion.py:97-102
         if self.draw_background:
             for batch in self.batches:
-                out = tile_fn(self.gather(x_in, batch))
+                out = tile_fn(self.gather(x_in, batch), batch) if with_boxes else tile_fn(self.gather(x_in, batch))
                 for i, (x, y, tw, th) in enumerate(batch):
                     o = out[i * N:(i + 1) * N]
                     if self.method == "md":                                       # multidiffusion.py:166-167
@@ -183,7 +185,7 @@ class BlendOracle:
                         buf[:, :, y:y + th, x:x + tw] += o * wgt
         fbuf = fmask = fcnt = None
         for i, r in enumerate(self.regions):
-            o = region_fn(x_in[r.sl], i)
+            o = region_fn(x_in[r.sl], i, r) if with_boxes else region_fn(x_in[r.sl], i)
             if r.blend_mode == BG:
                 if self.method == "md":                                           # multidiffusion.py:189-190
                     buf[r.sl] += o
