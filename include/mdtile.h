@@ -216,6 +216,8 @@ int mdtile_restandardize(int dtype, const void* d_x, const float* d_stats4, void
 /* split_tiles + get_best_tile_size (tilevae.py:390-462).  in_bboxes/out_bboxes: [4*n] as [x1,x2,y1,y2].
  * Returns the tile count (>=1) or a negative error; pass cap = capacity in tiles (call with cap=0 to query). */
 int mdtile_vae_split_tiles(int h, int w, int tile_size, int is_decoder, int* in_bboxes, int* out_bboxes, int cap);
+/* VAEHook.get_best_tile_size (scripts/tilevae.py:390-403): the size split_tiles shrinks a [lowerbound, upperbound] tile to. */
+int mdtile_vae_best_tile_size(int lowerbound, int upperbound);
 
 /* get_var_mean (tilevae.py:207-215): biased var & mean per (sample, group); x [B,C,HW]; out [B*groups] each.
  * Deterministic two-stage reduction (fp64 accumulators, no atomics); d_ws: mdtile_gn_stats_ws_size(B, groups) bytes. */
@@ -235,6 +237,7 @@ int mdtile_gn_apply(const float* d_x, float* d_y, int B, int C, int HW, int grou
                     mdtile_stream_t stream);
 /* standalone SiLU / residual add (queue tasks 'silu', 'add_res', tilevae.py:102-104, 614-616) */
 int mdtile_silu(const float* d_x, float* d_y, size_t n, mdtile_stream_t stream);
+int mdtile_tanh(const float* d_x, float* d_y, size_t n, mdtile_stream_t stream);   /* Decoder.tanh_out, scripts/tilevae.py:192-193 */
 int mdtile_add(const float* d_a, const float* d_b, float* d_y, size_t n, mdtile_stream_t stream);
 
 /* Conv tiles (queue tasks conv_in/conv1/conv2/nin_shortcut/upsample/conv_out/q/k/v/proj_out, tilevae.py:115-195).
@@ -346,7 +349,16 @@ int mdtile_vae_fast_input(const float* d_z, int N, int C, int H, int W, int tile
  *                          with other bands are packed, swapped (grouped ncclSend / ncclRecv) and summed in ascending rank order on
  *                          every side (bit-identical everywhere); then mdtile_blend_finalize.  d_scratch[i]: mdtile_halo_scratch_bytes.
  *   mdtile_allreduce_stats all-reduce(sum) of `count` doubles in place (slow-mode GroupNorm pooling across ranks, tilevae.py:320-335)
- *   mdtile_shard_bcast     `bytes` from rank `root` to all ranks (a region's model output to the bands that composite it) */
+ *   mdtile_shard_bcast     `bytes` from rank `root` to all ranks (a region's model output to the bands that composite it)
+ *   mdtile_shard_p2p       grouped point-to-point (one ncclGroup per call): ops[i][0 .. n_ops[i]) are local rank i's transfers; an op
+ *                          sends and / or receives (bytes == 0 skips that half); the k-th send of a to b pairs with b's k-th receive
+ *                          from a.  Carries the row halos of the sequence-parallel estimator (both directions in one group) and the
+ *                          gather of the decoded tile rectangles to the rank that returns the image
+ *   mdtile_shard_allgather every rank contributes `bytes`; d_recv[i] (nranks * bytes) holds them in rank order (K / V of the
+ *                          sequence-parallel estimator's attention, tile_utils/attn.py:55-67)
+ *   mdtile_shard_selfcheck bring-up check: all-reduce, broadcast, grouped ring send / receive (a self send / receive on one rank) and
+ *                          all-gather of small payloads, verified on the host; d_scratch[i] >= mdtile_shard_selfcheck_bytes(sh).
+ *                          MDTILE_SHARD_TRANSPORT=rccl makes a one-device context use a 1-rank RCCL communicator (it needs none). */
 typedef struct mdtile_shard mdtile_shard;
 mdtile_shard* mdtile_shard_init(int ndev, const int* dev_ids);
 int mdtile_shard_unique_id(void* id128);
@@ -359,6 +371,17 @@ int mdtile_halo_exchange(mdtile_shard* sh, float* const* d_partial, void* const*
                          const int* band_rows, const mdtile_stream_t* streams);
 int mdtile_allreduce_stats(mdtile_shard* sh, double* const* d_buf, int count, const mdtile_stream_t* streams);
 int mdtile_shard_bcast(mdtile_shard* sh, void* const* d_buf, size_t bytes, int root, const mdtile_stream_t* streams);
+typedef struct mdtile_p2p {
+    int peer;
+    const void* send;
+    size_t send_bytes;
+    void* recv;
+    size_t recv_bytes;
+} mdtile_p2p;
+int mdtile_shard_p2p(mdtile_shard* sh, const mdtile_p2p* const* ops, const int* n_ops, const mdtile_stream_t* streams);
+int mdtile_shard_allgather(mdtile_shard* sh, const void* const* d_send, void* const* d_recv, size_t bytes, const mdtile_stream_t* streams);
+size_t mdtile_shard_selfcheck_bytes(const mdtile_shard* sh);
+int mdtile_shard_selfcheck(mdtile_shard* sh, void* const* d_scratch, const mdtile_stream_t* streams);
 
 #ifdef __cplusplus
 }

@@ -194,6 +194,9 @@ static int best_tile_size(int lower, int upper) {
     return lower;
 }
 
+// get_best_tile_size (scripts/tilevae.py:390-403): smallest multiple of 32 / 16 / 8 / 4 / 2 >= lowerbound that still fits under upperbound
+extern "C" int mdtile_vae_best_tile_size(int lowerbound, int upperbound) { return best_tile_size(lowerbound, upperbound); }
+
 extern "C" int mdtile_vae_split_tiles(int h, int w, int tile_size, int is_decoder, int* in_bboxes, int* out_bboxes, int cap) {
     MDT_CHECK_ARG(h > 0 && w > 0 && tile_size > 0, "mdtile_vae_split_tiles: bad arguments");
     const int pad = is_decoder ? 11 : 32;

@@ -37,6 +37,7 @@ struct Rccl {
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -63,6 +64,7 @@ Rccl* rccl() {
     MDT_SYM(Recv, "ncclRecv")
     MDT_SYM(AllReduce, "ncclAllReduce")
     MDT_SYM(Broadcast, "ncclBroadcast")
+    MDT_SYM(AllGather, "ncclAllGather")
     MDT_SYM(GetErrorString, "ncclGetErrorString")
 #undef MDT_SYM
     return &R;
@@ -76,6 +78,24 @@ Rccl* rccl() {
             return MDTILE_E_HIP;                                                                \
         }                                                                                       \
     } while (0)
+
+// Calls between ncclGroupStart and ncclGroupEnd: remember the first failure, keep going to the GroupEnd (an open group would
+// poison every later RCCL call of the process), report afterwards.
+struct GroupScope {
+    Rccl* R;
+    ncclResult_t first = ncclSuccess;
+    const char* what = nullptr;
+    explicit GroupScope(Rccl* r) : R(r) { note(R->GroupStart(), "ncclGroupStart"); }
+    void note(ncclResult_t r, const char* w) {
+        if (r != ncclSuccess && first == ncclSuccess) { first = r; what = w; }
+    }
+    int end(const char* where) {
+        note(R->GroupEnd(), "ncclGroupEnd");
+        if (first == ncclSuccess) return MDTILE_OK;
+        mdt::set_error("%s: %s failed: %s", where, what, R->GetErrorString(first));
+        return MDTILE_E_HIP;
+    }
+};
 
 // slabs of rows [lo, hi) of every plane of a [planes, H, W] canvas <-> contiguous [planes, hi - lo, W]
 __global__ __launch_bounds__(256) void k_slab_pack(const float* __restrict__ canvas, float* __restrict__ slab, int H, int W, int lo, int rows) {
@@ -129,8 +149,25 @@ struct mdtile_shard {
     std::vector<int> dev;                       // device of each LOCAL rank
     std::vector<ncclComm_t> comm;
     std::vector<hipStream_t> stream;
-    std::vector<hipEvent_t> ev;                 // copy transport: "slabs of local rank i are packed"
+    std::vector<hipEvent_t> ev;                 // copy transport: "the send buffers of local rank i are ready"
+    std::vector<hipEvent_t> ev_done;            // copy transport: "local rank i has finished reading its peers' send buffers"
 };
+
+// copy transport, end of a call: the peers' send buffers may be overwritten by whatever their streams run next (the next
+// call's k_slab_pack, the caller's own kernels), so every stream waits until every reader has consumed them.
+static int copy_transport_fence(mdtile_shard* sh, const mdtile_stream_t* streams) {
+    for (int i = 0; i < sh->nlocal; ++i) {
+        MDT_HIP(hipSetDevice(sh->dev[i]));
+        MDT_HIP(hipEventRecord(sh->ev_done[i], streams ? as_stream(streams[i]) : sh->stream[i]));
+    }
+    for (int j = 0; j < sh->nlocal; ++j) {
+        MDT_HIP(hipSetDevice(sh->dev[j]));
+        hipStream_t st = streams ? as_stream(streams[j]) : sh->stream[j];
+        for (int i = 0; i < sh->nlocal; ++i)
+            if (i != j) MDT_HIP(hipStreamWaitEvent(st, sh->ev_done[i], 0));
+    }
+    return MDTILE_OK;
+}
 
 static void shard_free(mdtile_shard* sh) {
     if (!sh) return;
@@ -141,6 +178,7 @@ static void shard_free(mdtile_shard* sh) {
         if (i < (int)sh->comm.size() && sh->comm[i] && rccl()) rccl()->CommDestroy(sh->comm[i]);
         if (i < (int)sh->stream.size() && sh->stream[i]) (void)hipStreamDestroy(sh->stream[i]);
         if (i < (int)sh->ev.size() && sh->ev[i]) (void)hipEventDestroy(sh->ev[i]);
+        if (i < (int)sh->ev_done.size() && sh->ev_done[i]) (void)hipEventDestroy(sh->ev_done[i]);
     }
     (void)hipSetDevice(cur);
     delete sh;
@@ -151,9 +189,11 @@ static bool make_streams(mdtile_shard* sh) {
     (void)hipGetDevice(&cur);
     sh->stream.assign(sh->nlocal, nullptr);
     sh->ev.assign(sh->nlocal, nullptr);
+    sh->ev_done.assign(sh->nlocal, nullptr);
     for (int i = 0; i < sh->nlocal; ++i) {
         if (hipSetDevice(sh->dev[i]) != hipSuccess || hipStreamCreateWithFlags(&sh->stream[i], hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&sh->ev[i], hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&sh->ev[i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&sh->ev_done[i], hipEventDisableTiming) != hipSuccess) {
             (void)hipSetDevice(cur);
             return false;
         }
@@ -175,7 +215,9 @@ extern "C" mdtile_shard* mdtile_shard_init(int ndev, const int* dev_ids) {
     for (int i = 0; i < ndev; ++i)
         for (int j = 0; j < i; ++j) repeats |= dev_ids[i] == dev_ids[j];
     const char* env = getenv("MDTILE_SHARD_TRANSPORT");
-    sh->copy_transport = repeats || ndev == 1 || (env && strcmp(env, "copy") == 0);
+    // one listed device needs no transport at all; MDTILE_SHARD_TRANSPORT=rccl still builds a 1-rank communicator (bring-up checks)
+    const bool force_rccl = env && strcmp(env, "rccl") == 0;
+    sh->copy_transport = repeats || (ndev == 1 && !force_rccl) || (env && strcmp(env, "copy") == 0);
     if (!make_streams(sh)) {
         set_error("mdtile_shard_init: stream / event creation failed");
         shard_free(sh);
@@ -333,18 +375,20 @@ extern "C" int mdtile_halo_exchange(mdtile_shard* sh, float* const* d_partial, v
                 MDT_HIP(hipMemcpyAsync(recvp[i][k], sendp[j][kk], bytes, hipMemcpyDeviceToDevice, st));
             }
         }
+        int rc = copy_transport_fence(sh, streams);
+        if (rc != MDTILE_OK) return rc;
     } else {
-        Rccl* R = rccl();
-        MDT_NCCL(R->GroupStart());
+        GroupScope G(rccl());
         for (int i = 0; i < sh->nlocal; ++i) {
             hipStream_t st = streams ? as_stream(streams[i]) : sh->stream[i];
             for (int k = 0; k < sets[i].n; ++k) {
                 const size_t n = (size_t)(sets[i].hi[k] - sets[i].lo[k]) * W * planes;
-                MDT_NCCL(R->Send(sendp[i][k], n, ncclFloat32, sets[i].peer[k], sh->comm[i], st));
-                MDT_NCCL(R->Recv(recvp[i][k], n, ncclFloat32, sets[i].peer[k], sh->comm[i], st));
+                G.note(G.R->Send(sendp[i][k], n, ncclFloat32, sets[i].peer[k], sh->comm[i], st), "ncclSend");
+                G.note(G.R->Recv(recvp[i][k], n, ncclFloat32, sets[i].peer[k], sh->comm[i], st), "ncclRecv");
             }
         }
-        MDT_NCCL(R->GroupEnd());
+        int rc = G.end("mdtile_halo_exchange");
+        if (rc != MDTILE_OK) return rc;
     }
     // 3. sum in ascending rank order
     for (int i = 0; i < sh->nlocal; ++i) {
@@ -369,7 +413,7 @@ extern "C" int mdtile_halo_exchange(mdtile_shard* sh, float* const* d_partial, v
 // sequence-parallel estimator's fp64 (sum, sum of squares) pairs).  In place.
 extern "C" int mdtile_allreduce_stats(mdtile_shard* sh, double* const* d_buf, int count, const mdtile_stream_t* streams) {
     MDT_CHECK_ARG(sh && d_buf && count > 0, "mdtile_allreduce_stats: bad arguments");
-    if (sh->nranks == 1) return MDTILE_OK;
+    if (sh->nranks == 1 && sh->copy_transport) return MDTILE_OK;
     if (sh->copy_transport) {
         // single process, repeated devices: sum on local rank 0's stream in rank order, then copy back
         int cur = 0;
@@ -395,18 +439,16 @@ extern "C" int mdtile_allreduce_stats(mdtile_shard* sh, double* const* d_buf, in
         MDT_HIP(hipSetDevice(cur));
         return MDTILE_OK;
     }
-    Rccl* R = rccl();
-    MDT_NCCL(R->GroupStart());
+    GroupScope G(rccl());
     for (int i = 0; i < sh->nlocal; ++i)
-        MDT_NCCL(R->AllReduce(d_buf[i], d_buf[i], count, ncclFloat64, ncclSum, sh->comm[i], streams ? as_stream(streams[i]) : sh->stream[i]));
-    MDT_NCCL(R->GroupEnd());
-    return MDTILE_OK;
+        G.note(G.R->AllReduce(d_buf[i], d_buf[i], count, ncclFloat64, ncclSum, sh->comm[i], streams ? as_stream(streams[i]) : sh->stream[i]), "ncclAllReduce");
+    return G.end("mdtile_allreduce_stats");
 }
 
 // broadcast `bytes` from rank `root` to every rank (a region's model output to the bands that composite it, cfg5)
 extern "C" int mdtile_shard_bcast(mdtile_shard* sh, void* const* d_buf, size_t bytes, int root, const mdtile_stream_t* streams) {
     MDT_CHECK_ARG(sh && d_buf && root >= 0 && root < sh->nranks, "mdtile_shard_bcast: bad arguments");
-    if (sh->nranks == 1 || bytes == 0) return MDTILE_OK;
+    if ((sh->nranks == 1 && sh->copy_transport) || bytes == 0) return MDTILE_OK;
     if (sh->copy_transport) {
         const int jr = root - sh->first;
         MDT_CHECK_ARG(jr >= 0 && jr < sh->nlocal, "mdtile_shard_bcast: the copy transport needs every rank in this process");
@@ -422,13 +464,218 @@ extern "C" int mdtile_shard_bcast(mdtile_shard* sh, void* const* d_buf, size_t b
             MDT_HIP(hipStreamWaitEvent(st, sh->ev[jr], 0));
             MDT_HIP(hipMemcpyAsync(d_buf[i], d_buf[jr], bytes, hipMemcpyDeviceToDevice, st));
         }
+        int rc = copy_transport_fence(sh, streams);
         MDT_HIP(hipSetDevice(cur));
-        return MDTILE_OK;
+        return rc;
     }
-    Rccl* R = rccl();
-    MDT_NCCL(R->GroupStart());
+    GroupScope G(rccl());
     for (int i = 0; i < sh->nlocal; ++i)
-        MDT_NCCL(R->Broadcast(d_buf[i], d_buf[i], bytes, ncclUint8, root, sh->comm[i], streams ? as_stream(streams[i]) : sh->stream[i]));
-    MDT_NCCL(R->GroupEnd());
+        G.note(G.R->Broadcast(d_buf[i], d_buf[i], bytes, ncclUint8, root, sh->comm[i], streams ? as_stream(streams[i]) : sh->stream[i]), "ncclBroadcast");
+    return G.end("mdtile_shard_bcast");
+}
+
+// Grouped point-to-point: ops[i][0 .. n_ops[i]) belong to LOCAL rank i; every op may send and / or receive (bytes == 0 skips that
+// half).  The k-th send of rank a to rank b pairs with the k-th receive of rank b from rank a.  One ncclGroup for the whole call
+// (both halo directions of a row band, every tile rectangle of an image gather ... travel concurrently over their own xGMI links).
+extern "C" int mdtile_shard_p2p(mdtile_shard* sh, const mdtile_p2p* const* ops, const int* n_ops, const mdtile_stream_t* streams) {
+    MDT_CHECK_ARG(sh && ops && n_ops, "mdtile_shard_p2p: null argument");
+    for (int i = 0; i < sh->nlocal; ++i)
+        for (int k = 0; k < n_ops[i]; ++k) {
+            const mdtile_p2p& o = ops[i][k];
+            MDT_CHECK_ARG(o.peer >= 0 && o.peer < sh->nranks && (o.send_bytes == 0 || o.send) && (o.recv_bytes == 0 || o.recv),
+                          "mdtile_shard_p2p: bad op %d of local rank %d (peer %d)", k, i, o.peer);
+        }
+    if (sh->copy_transport) {
+        int cur = 0;
+        MDT_HIP(hipGetDevice(&cur));
+        for (int i = 0; i < sh->nlocal; ++i) {
+            MDT_HIP(hipSetDevice(sh->dev[i]));
+            MDT_HIP(hipEventRecord(sh->ev[i], streams ? as_stream(streams[i]) : sh->stream[i]));
+        }
+        for (int i = 0; i < sh->nlocal; ++i) {
+            hipStream_t st = streams ? as_stream(streams[i]) : sh->stream[i];
+            MDT_HIP(hipSetDevice(sh->dev[i]));
+            for (int k = 0; k < n_ops[i]; ++k) {
+                const mdtile_p2p& o = ops[i][k];
+                if (o.recv_bytes == 0) continue;
+                const int j = o.peer - sh->first;
+                MDT_CHECK_ARG(j >= 0 && j < sh->nlocal, "mdtile_shard_p2p: the copy transport needs every rank in this process");
+                int ord = 0;                                      // this is my ord-th receive from that peer ...
+                for (int q = 0; q < k; ++q) ord += ops[i][q].peer == o.peer && ops[i][q].recv_bytes > 0;
+                const mdtile_p2p* src = nullptr;                  // ... it pairs with the peer's ord-th send to me
+                for (int q = 0, seen = 0; q < n_ops[j] && !src; ++q)
+                    if (ops[j][q].peer == sh->first + i && ops[j][q].send_bytes > 0 && seen++ == ord) src = &ops[j][q];
+                MDT_CHECK_ARG(src && src->send_bytes == o.recv_bytes, "mdtile_shard_p2p: receive %d of rank %d has no matching send", k, sh->first + i);
+                MDT_HIP(hipStreamWaitEvent(st, sh->ev[j], 0));
+                MDT_HIP(hipMemcpyAsync(o.recv, src->send, o.recv_bytes, hipMemcpyDeviceToDevice, st));
+            }
+        }
+        int rc = copy_transport_fence(sh, streams);
+        MDT_HIP(hipSetDevice(cur));
+        return rc;
+    }
+    GroupScope G(rccl());
+    for (int i = 0; i < sh->nlocal; ++i) {
+        hipStream_t st = streams ? as_stream(streams[i]) : sh->stream[i];
+        for (int k = 0; k < n_ops[i]; ++k) {
+            const mdtile_p2p& o = ops[i][k];
+            if (o.send_bytes) G.note(G.R->Send(o.send, o.send_bytes, ncclUint8, o.peer, sh->comm[i], st), "ncclSend");
+            if (o.recv_bytes) G.note(G.R->Recv(o.recv, o.recv_bytes, ncclUint8, o.peer, sh->comm[i], st), "ncclRecv");
+        }
+    }
+    return G.end("mdtile_shard_p2p");
+}
+
+// all-gather: every rank contributes `bytes`; d_recv[i] (nranks * bytes) receives them in rank order.
+extern "C" int mdtile_shard_allgather(mdtile_shard* sh, const void* const* d_send, void* const* d_recv, size_t bytes, const mdtile_stream_t* streams) {
+    MDT_CHECK_ARG(sh && d_send && d_recv, "mdtile_shard_allgather: null argument");
+    if (bytes == 0) return MDTILE_OK;
+    if (sh->copy_transport) {
+        MDT_CHECK_ARG(sh->nlocal == sh->nranks, "mdtile_shard_allgather: the copy transport needs every rank in this process");
+        int cur = 0;
+        MDT_HIP(hipGetDevice(&cur));
+        for (int i = 0; i < sh->nlocal; ++i) {
+            MDT_HIP(hipSetDevice(sh->dev[i]));
+            MDT_HIP(hipEventRecord(sh->ev[i], streams ? as_stream(streams[i]) : sh->stream[i]));
+        }
+        for (int i = 0; i < sh->nlocal; ++i) {
+            hipStream_t st = streams ? as_stream(streams[i]) : sh->stream[i];
+            MDT_HIP(hipSetDevice(sh->dev[i]));
+            for (int j = 0; j < sh->nlocal; ++j) {
+                if (j != i) MDT_HIP(hipStreamWaitEvent(st, sh->ev[j], 0));
+                MDT_HIP(hipMemcpyAsync(static_cast<char*>(d_recv[i]) + (size_t)j * bytes, d_send[j], bytes, hipMemcpyDeviceToDevice, st));
+            }
+        }
+        int rc = copy_transport_fence(sh, streams);
+        MDT_HIP(hipSetDevice(cur));
+        return rc;
+    }
+    GroupScope G(rccl());
+    for (int i = 0; i < sh->nlocal; ++i)
+        G.note(G.R->AllGather(d_send[i], d_recv[i], bytes, ncclUint8, sh->comm[i], streams ? as_stream(streams[i]) : sh->stream[i]), "ncclAllGather");
+    return G.end("mdtile_shard_allgather");
+}
+
+namespace {
+// selfcheck payloads: word k of rank r
+__host__ __device__ inline unsigned chk_word(int what, int r, int k) { return 0x9E3779B9u * (unsigned)(what * 131 + r * 17 + 1) + (unsigned)k * 2654435761u; }
+__global__ void k_chk_fill(unsigned* p, int what, int r, int n) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) p[k] = chk_word(what, r, k);
+}
+__global__ void k_chk_fill_f64(double* p, int r, int n) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) p[k] = (double)(r + 1) * 0.5 + (double)k;
+}
+}  // namespace
+
+// Bring-up check of a context (any rank count, both transports): one all-reduce, one broadcast, one grouped ring send / receive
+// (a self send / receive when the context has one rank) and one all-gather on small payloads, results verified on the host.
+// d_scratch[i]: >= mdtile_shard_selfcheck_bytes(sh) device bytes per local rank.  Synchronises the streams it uses.
+extern "C" size_t mdtile_shard_selfcheck_bytes(const mdtile_shard* sh) { return sh ? (size_t)(4 + sh->nranks) * 1024 : 0; }
+
+extern "C" int mdtile_shard_selfcheck(mdtile_shard* sh, void* const* d_scratch, const mdtile_stream_t* streams) {
+    MDT_CHECK_ARG(sh && d_scratch, "mdtile_shard_selfcheck: null argument");
+    constexpr int NW = 256;                                // 1 KiB payloads
+    const int nl = sh->nlocal, n = sh->nranks;
+    int cur = 0;
+    MDT_HIP(hipGetDevice(&cur));
+    auto st_of = [&](int i) { return streams ? as_stream(streams[i]) : sh->stream[i]; };
+    auto at = [&](int i, int kib) { return static_cast<char*>(d_scratch[i]) + (size_t)kib * 1024; };
+    std::vector<unsigned> host(NW * (size_t)(n > 1 ? n : 1));
+    std::vector<double> hostd(8);
+    auto sync_all = [&]() -> int {
+        for (int i = 0; i < nl; ++i) {
+            MDT_HIP(hipSetDevice(sh->dev[i]));
+            MDT_HIP(hipStreamSynchronize(st_of(i)));
+        }
+        return MDTILE_OK;
+    };
+    int rc;
+    // (1) all-reduce of 8 doubles: word k becomes sum_r ((r + 1) / 2 + k)
+    for (int i = 0; i < nl; ++i) {
+        MDT_HIP(hipSetDevice(sh->dev[i]));
+        hipLaunchKernelGGL(k_chk_fill_f64, dim3(1), dim3(64), 0, st_of(i), reinterpret_cast<double*>(at(i, 0)), sh->first + i, 8);
+    }
+    {
+        std::vector<double*> bufs(nl);
+        for (int i = 0; i < nl; ++i) bufs[i] = reinterpret_cast<double*>(at(i, 0));
+        if ((rc = mdtile_allreduce_stats(sh, bufs.data(), 8, streams)) != MDTILE_OK) return rc;
+    }
+    if ((rc = sync_all()) != MDTILE_OK) return rc;
+    for (int i = 0; i < nl; ++i) {
+        MDT_HIP(hipSetDevice(sh->dev[i]));
+        MDT_HIP(hipMemcpy(hostd.data(), at(i, 0), 8 * sizeof(double), hipMemcpyDeviceToHost));
+        for (int k = 0; k < 8; ++k) {
+            const double want = 0.25 * n * (n + 1) + (double)k * n;
+            MDT_CHECK_ARG(hostd[k] == want, "mdtile_shard_selfcheck: all-reduce word %d of rank %d = %.17g, expected %.17g", k, sh->first + i, hostd[k], want);
+        }
+    }
+    // (2) broadcast from the last rank
+    for (int i = 0; i < nl; ++i) {
+        MDT_HIP(hipSetDevice(sh->dev[i]));
+        hipLaunchKernelGGL(k_chk_fill, dim3(1), dim3(NW), 0, st_of(i), reinterpret_cast<unsigned*>(at(i, 1)), 2, sh->first + i, NW);
+    }
+    {
+        std::vector<void*> bufs(nl);
+        for (int i = 0; i < nl; ++i) bufs[i] = at(i, 1);
+        if ((rc = mdtile_shard_bcast(sh, bufs.data(), NW * 4, n - 1, streams)) != MDTILE_OK) return rc;
+    }
+    if ((rc = sync_all()) != MDTILE_OK) return rc;
+    for (int i = 0; i < nl; ++i) {
+        MDT_HIP(hipSetDevice(sh->dev[i]));
+        MDT_HIP(hipMemcpy(host.data(), at(i, 1), NW * 4, hipMemcpyDeviceToHost));
+        for (int k = 0; k < NW; ++k)
+            MDT_CHECK_ARG(host[k] == chk_word(2, n - 1, k), "mdtile_shard_selfcheck: broadcast word %d wrong on rank %d", k, sh->first + i);
+    }
+    // (3) ring: send to rank + 1, receive from rank - 1, one group (one rank: a self send / receive)
+    {
+        std::vector<std::vector<mdtile_p2p>> mine(nl);
+        std::vector<const mdtile_p2p*> ops(nl);
+        std::vector<int> cnt(nl);
+        for (int i = 0; i < nl; ++i) {
+            MDT_HIP(hipSetDevice(sh->dev[i]));
+            const int me = sh->first + i, next = (me + 1) % n, prev = (me + n - 1) % n;
+            hipLaunchKernelGGL(k_chk_fill, dim3(1), dim3(NW), 0, st_of(i), reinterpret_cast<unsigned*>(at(i, 2)), 3, me, NW);
+            MDT_HIP(hipMemsetAsync(at(i, 3), 0, NW * 4, st_of(i)));
+            if (next == prev) {         // one or two ranks: the same peer on both sides, one op carries both halves
+                mine[i] = {mdtile_p2p{next, at(i, 2), NW * 4, at(i, 3), NW * 4}};
+            } else {
+                mine[i] = {mdtile_p2p{next, at(i, 2), NW * 4, nullptr, 0}, mdtile_p2p{prev, nullptr, 0, at(i, 3), NW * 4}};
+            }
+            ops[i] = mine[i].data();
+            cnt[i] = (int)mine[i].size();
+        }
+        if ((rc = mdtile_shard_p2p(sh, ops.data(), cnt.data(), streams)) != MDTILE_OK) return rc;
+    }
+    if ((rc = sync_all()) != MDTILE_OK) return rc;
+    for (int i = 0; i < nl; ++i) {
+        MDT_HIP(hipSetDevice(sh->dev[i]));
+        MDT_HIP(hipMemcpy(host.data(), at(i, 3), NW * 4, hipMemcpyDeviceToHost));
+        const int from = (sh->first + i + n - 1) % n;
+        for (int k = 0; k < NW; ++k)
+            MDT_CHECK_ARG(host[k] == chk_word(3, from, k), "mdtile_shard_selfcheck: ring word %d wrong on rank %d", k, sh->first + i);
+    }
+    // (4) all-gather of 1 KiB per rank
+    {
+        std::vector<const void*> snd(nl);
+        std::vector<void*> rcv(nl);
+        for (int i = 0; i < nl; ++i) {
+            MDT_HIP(hipSetDevice(sh->dev[i]));
+            hipLaunchKernelGGL(k_chk_fill, dim3(1), dim3(NW), 0, st_of(i), reinterpret_cast<unsigned*>(at(i, 2)), 4, sh->first + i, NW);
+            snd[i] = at(i, 2);
+            rcv[i] = at(i, 4);
+        }
+        if ((rc = mdtile_shard_allgather(sh, snd.data(), rcv.data(), NW * 4, streams)) != MDTILE_OK) return rc;
+    }
+    if ((rc = sync_all()) != MDTILE_OK) return rc;
+    for (int i = 0; i < nl; ++i) {
+        MDT_HIP(hipSetDevice(sh->dev[i]));
+        MDT_HIP(hipMemcpy(host.data(), at(i, 4), (size_t)n * NW * 4, hipMemcpyDeviceToHost));
+        for (int r = 0; r < n; ++r)
+            for (int k = 0; k < NW; ++k)
+                MDT_CHECK_ARG(host[(size_t)r * NW + k] == chk_word(4, r, k), "mdtile_shard_selfcheck: all-gather word %d of rank %d wrong on rank %d", k, r, sh->first + i);
+    }
+    MDT_HIP(hipSetDevice(cur));
     return MDTILE_OK;
 }

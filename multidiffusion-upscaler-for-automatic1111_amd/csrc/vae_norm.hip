@@ -171,21 +171,25 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x, f
     }
 }
 
-template <int OP>  // 0 = silu(a), 1 = a + b
+template <int OP> __device__ __forceinline__ float eltwise_f(float a, float b) {
+    return OP == 0 ? silu_f(a) : OP == 1 ? a + b : tanhf(a);
+}
+
+template <int OP>  // 0 = silu(a), 1 = a + b, 2 = tanh(a)
 __global__ __launch_bounds__(256) void k_eltwise(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, size_t n) {
     const size_t n4 = n >> 2;
-    const bool vec = ((reinterpret_cast<size_t>(a) | reinterpret_cast<size_t>(y) | (OP ? reinterpret_cast<size_t>(b) : 0)) & 15) == 0;
+    const bool vec = ((reinterpret_cast<size_t>(a) | reinterpret_cast<size_t>(y) | (OP == 1 ? reinterpret_cast<size_t>(b) : 0)) & 15) == 0;
     const size_t stride = (size_t)gridDim.x * 256;
     if (vec) {
         for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
             float4 v = reinterpret_cast<const float4*>(a)[i], o;
-            if (OP == 0) { o.x = silu_f(v.x); o.y = silu_f(v.y); o.z = silu_f(v.z); o.w = silu_f(v.w); }
+            if (OP != 1) { o.x = eltwise_f<OP>(v.x, 0.f); o.y = eltwise_f<OP>(v.y, 0.f); o.z = eltwise_f<OP>(v.z, 0.f); o.w = eltwise_f<OP>(v.w, 0.f); }
             else { float4 w = reinterpret_cast<const float4*>(b)[i]; o.x = v.x + w.x; o.y = v.y + w.y; o.z = v.z + w.z; o.w = v.w + w.w; }
             reinterpret_cast<float4*>(y)[i] = o;
         }
-        for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) y[i] = OP == 0 ? silu_f(a[i]) : a[i] + b[i];
+        for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) y[i] = eltwise_f<OP>(a[i], OP == 1 ? b[i] : 0.f);
     } else {
-        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) y[i] = OP == 0 ? silu_f(a[i]) : a[i] + b[i];
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) y[i] = eltwise_f<OP>(a[i], OP == 1 ? b[i] : 0.f);
     }
 }
 
@@ -381,6 +385,15 @@ extern "C" int mdtile_silu(const float* d_x, float* d_y, size_t n, mdtile_stream
     MDT_CHECK_ARG(d_x && d_y, "mdtile_silu: null argument");
     if (n == 0) return MDTILE_OK;
     hipLaunchKernelGGL(k_eltwise<0>, dim3(eltwise_grid(n)), dim3(256), 0, as_stream(stream), d_x, (const float*)nullptr, d_y, n);
+    MDT_LAUNCH_CHECK();
+    return MDTILE_OK;
+}
+
+// Decoder.tanh_out (ldm Decoder.forward; upstream queues it as the last task, scripts/tilevae.py:192-193)
+extern "C" int mdtile_tanh(const float* d_x, float* d_y, size_t n, mdtile_stream_t stream) {
+    MDT_CHECK_ARG(d_x && d_y, "mdtile_tanh: null argument");
+    if (n == 0) return MDTILE_OK;
+    hipLaunchKernelGGL(k_eltwise<2>, dim3(eltwise_grid(n)), dim3(256), 0, as_stream(stream), d_x, (const float*)nullptr, d_y, n);
     MDT_LAUNCH_CHECK();
     return MDTILE_OK;
 }

@@ -39,6 +39,10 @@ class _Region(ctypes.Structure):
                 ("out", c_void_p), ("weight", c_void_p)]
 
 
+class _P2P(ctypes.Structure):
+    _fields_ = [("peer", c_int), ("send", c_void_p), ("send_bytes", c_size_t), ("recv", c_void_p), ("recv_bytes", c_size_t)]
+
+
 class _BlendArgs(ctypes.Structure):
     _fields_ = [("method", c_int), ("dtype", c_int), ("N", c_int), ("C", c_int), ("flags", c_int),
                 ("tile_lo", c_int), ("tile_hi", c_int), ("row_lo", c_int), ("row_hi", c_int),
@@ -81,18 +85,24 @@ _SIGNATURES = {
     "mdtile_halo_exchange": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_int, c_int, c_int, c_int, _IP, POINTER(c_void_p)]),
     "mdtile_allreduce_stats": (c_int, [c_void_p, POINTER(c_void_p), c_int, POINTER(c_void_p)]),
     "mdtile_shard_bcast": (c_int, [c_void_p, POINTER(c_void_p), c_size_t, c_int, POINTER(c_void_p)]),
+    "mdtile_shard_p2p": (c_int, [c_void_p, POINTER(POINTER(_P2P)), _IP, POINTER(c_void_p)]),
+    "mdtile_shard_allgather": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_size_t, POINTER(c_void_p)]),
+    "mdtile_shard_selfcheck_bytes": (c_size_t, [c_void_p]),
+    "mdtile_shard_selfcheck": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p)]),
     "mdtile_window_blend": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mdtile_dilated_gather": (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, _IP, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mdtile_demofusion_combine": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "mdtile_depthwise_blur": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "mdtile_restandardize": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mdtile_vae_split_tiles": (c_int, [c_int, c_int, c_int, c_int, _IP, _IP, c_int]),
+    "mdtile_vae_best_tile_size": (c_int, [c_int, c_int]),
     "mdtile_gn_stats_ws_size": (c_size_t, [c_int, c_int]),
     "mdtile_gn_stats": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mdtile_gn_pool": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "mdtile_gn_apply": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_float, c_int, c_void_p]),
     "mdtile_silu": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mdtile_tanh": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "mdtile_add": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mdtile_conv_packed_size": (c_size_t, [c_int, c_int, c_int]),
     "mdtile_conv_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
@@ -529,6 +539,11 @@ def vae_split_tiles(h: int, w: int, tile_size: int, is_decoder: bool = True):
     return [fi[4 * i:4 * i + 4] for i in range(n)], [fo[4 * i:4 * i + 4] for i in range(n)]
 
 
+def vae_best_tile_size(lowerbound: int, upperbound: int) -> int:
+    """get_best_tile_size (scripts/tilevae.py:390-403).  Host ints only."""
+    return int(lib().mdtile_vae_best_tile_size(int(lowerbound), int(upperbound)))
+
+
 def gn_stats(x: torch.Tensor, groups: int = 32):
     """get_var_mean (tilevae.py:207-215) -> (var, mean), each [B*groups]."""
     _dev_tensor(x, "x", torch.float32)
@@ -651,6 +666,14 @@ def silu(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _dev_tensor(x, "x", torch.float32)
     out = torch.empty_like(x) if out is None else out
     _check(lib().mdtile_silu(_p(x), _p(out), x.numel(), _stream()), "mdtile_silu")
+    return out
+
+
+def tanh(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Decoder.tanh_out (the queue's last task, scripts/tilevae.py:192-193)."""
+    _dev_tensor(x, "x", torch.float32)
+    out = torch.empty_like(x) if out is None else out
+    _check(lib().mdtile_tanh(_p(x), _p(out), x.numel(), _stream()), "mdtile_tanh")
     return out
 
 
@@ -954,7 +977,47 @@ class Shard:
         pp = (c_void_p * self.nlocal)(*[t.data_ptr() for t in bufs])
         _check(lib().mdtile_shard_bcast(self._h, pp, bufs[0].numel() * bufs[0].element_size(), int(root), self._streams(streams)), "mdtile_shard_bcast")
 
-    def __del__(self):
+    def p2p(self, ops: Sequence[Sequence[Tuple[int, Optional[torch.Tensor], Optional[torch.Tensor]]]], streams=None) -> None:
+        """Grouped point-to-point: ops[i] = [(peer rank, tensor to send or None, tensor to receive into or None), ...] of local
+        rank i; every tensor contiguous on that rank's device.  One ncclGroup for the whole call."""
+        assert len(ops) == self.nlocal
+        arrs, keep = [], []
+        for lst in ops:
+            a = (_P2P * max(1, len(lst)))()
+            for k, (peer, snd, rcv) in enumerate(lst):
+                for nm, t in (("send", snd), ("recv", rcv)):
+                    if t is not None:
+                        _dev_tensor(t, nm)
+                keep.append((snd, rcv))
+                a[k] = _P2P(int(peer), None if snd is None else snd.data_ptr(), 0 if snd is None else snd.numel() * snd.element_size(),
+                            None if rcv is None else rcv.data_ptr(), 0 if rcv is None else rcv.numel() * rcv.element_size())
+            arrs.append(a)
+        pp = (POINTER(_P2P) * self.nlocal)(*[ctypes.cast(a, POINTER(_P2P)) for a in arrs])
+        cnt = (c_int * self.nlocal)(*[len(lst) for lst in ops])
+        _check(lib().mdtile_shard_p2p(self._h, pp, cnt, self._streams(streams)), "mdtile_shard_p2p")
+
+    def allgather(self, sends: Sequence[torch.Tensor], streams=None) -> List[torch.Tensor]:
+        """Every rank contributes a tensor of one common shape; returns per local rank the [nranks, *shape] stack in rank order."""
+        outs = []
+        for t in sends:
+            _dev_tensor(t, "send")
+            outs.append(torch.empty((self.nranks,) + tuple(t.shape), dtype=t.dtype, device=t.device))
+        ss = (c_void_p * self.nlocal)(*[t.data_ptr() for t in sends])
+        rr = (c_void_p * self.nlocal)(*[t.data_ptr() for t in outs])
+        _check(lib().mdtile_shard_allgather(self._h, ss, rr, sends[0].numel() * sends[0].element_size(), self._streams(streams)), "mdtile_shard_allgather")
+        return outs
+
+    def selfcheck(self, streams=None) -> None:
+        """Bring-up check (all-reduce, broadcast, grouped ring send / receive, all-gather; verified on the host).  Raises on failure."""
+        n = int(lib().mdtile_shard_selfcheck_bytes(self._h))
+        bufs = [torch.empty(n, dtype=torch.uint8, device=torch.device("cuda", d)) for d in self.devices]
+        pp = (c_void_p * self.nlocal)(*[t.data_ptr() for t in bufs])
+        _check(lib().mdtile_shard_selfcheck(self._h, pp, self._streams(streams)), "mdtile_shard_selfcheck")
+
+    def destroy(self) -> None:
         h, self._h = getattr(self, "_h", None), None
         if h and _lib is not None:
             _lib.mdtile_shard_destroy(h)
+
+    def __del__(self):
+        self.destroy()

@@ -38,57 +38,47 @@ def row_bounds(H: int, world: int) -> List[int]:
 
 
 class BandComm:
-    """Neighbour / group communication of one band.  Device tensors go straight to RCCL ("nccl"); with a backend that
-    cannot move device memory (gloo: CPU tests, single-GPU multi-process checks) they are staged through the host."""
+    """Neighbour / group communication of one band, on the job's data plane (mdtile/sharding.py comm_*): the engine's own RCCL
+    communicator behind the C ABI when the process has one (mdtile_shard_p2p / _allreduce_stats / _allgather on torch's current
+    stream), torch.distributed otherwise (gloo in the CPU tests and single-GPU multi-process checks: staged through the host)."""
 
     def __init__(self, rank: int, world: int, group=None):
         self.rank, self.world, self.group = rank, world, group
-        self.host_staged = world > 1 and dist.get_backend(group) == "gloo"
-
-    def _out(self, t: torch.Tensor) -> torch.Tensor:
-        t = t.contiguous()
-        return t.cpu() if (self.host_staged and t.is_cuda) else t
-
-    def _like(self, t: torch.Tensor) -> torch.Tensor:
-        return torch.empty(t.shape, dtype=t.dtype, device="cpu" if self.host_staged else t.device)
 
     def exchange_halos(self, x: torch.Tensor, ht: int, hb: int, rows: int) -> None:
         """Refresh the halo slots of x [B, C, ht + rows + hb, W] in place: my first own row goes to the upper neighbour's
-        bottom slot, my last own row to the lower neighbour's top slot, and vice versa."""
+        bottom slot, my last own row to the lower neighbour's top slot, and vice versa -- both directions in ONE grouped
+        exchange (with two ranks both halves meet the same peer; xGMI links are per pair, so up and down overlap)."""
         if self.world == 1 or (ht == 0 and hb == 0):
             return
+        from mdtile import sharding
         ops, recvs = [], []
         if ht:
-            send = self._out(x[:, :, ht:ht + 1, :])
-            recv = self._like(send)
-            ops += [dist.P2POp(dist.isend, send, self.rank - 1, group=self.group), dist.P2POp(dist.irecv, recv, self.rank - 1, group=self.group)]
+            send = x[:, :, ht:ht + 1, :].contiguous()
+            recv = torch.empty_like(send)
+            ops.append((self.rank - 1, send, recv))
             recvs.append((0, recv))
         if hb:
-            send = self._out(x[:, :, ht + rows - 1:ht + rows, :])
-            recv = self._like(send)
-            ops += [dist.P2POp(dist.isend, send, self.rank + 1, group=self.group), dist.P2POp(dist.irecv, recv, self.rank + 1, group=self.group)]
+            send = x[:, :, ht + rows - 1:ht + rows, :].contiguous()
+            recv = torch.empty_like(send)
+            ops.append((self.rank + 1, send, recv))
             recvs.append((ht + rows, recv))
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
+        sharding.comm_p2p(ops, self.group)
         for row, recv in recvs:
             x[:, :, row:row + 1, :].copy_(recv)
 
     def allreduce_sum(self, t: torch.Tensor) -> torch.Tensor:
         if self.world == 1:
             return t
-        if self.host_staged and t.is_cuda:
-            h = t.cpu()
-            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
-            t.copy_(h)
-        else:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-        return t
+        from mdtile import sharding
+        return sharding.comm_allreduce_sum(t, self.group)
 
     def allgather_cat(self, t: torch.Tensor, dim: int, sizes: Sequence[int]) -> torch.Tensor:
         """Concatenate every rank's `t` along `dim`; rank r contributes sizes[r] entries along that axis (known to all
         ranks from the partition, so uneven bands are padded to the largest and trimmed)."""
         if self.world == 1:
             return t
+        from mdtile import sharding
         assert t.shape[dim] == sizes[self.rank]
         big = max(sizes)
         src = t
@@ -96,11 +86,8 @@ class BandComm:
             pad_shape = list(t.shape)
             pad_shape[dim] = big - t.shape[dim]
             src = torch.cat([t, t.new_zeros(pad_shape)], dim=dim)
-        src = self._out(src)
-        parts = [torch.empty_like(src) for _ in range(self.world)]
-        dist.all_gather(parts, src, group=self.group)
-        out = torch.cat([p.narrow(dim, 0, sizes[r]) for r, p in enumerate(parts)], dim=dim)
-        return out.to(t.device) if out.device != t.device else out
+        parts = sharding.comm_allgather(src, self.world, self.group)
+        return torch.cat([p.narrow(dim, 0, sizes[r]) for r, p in enumerate(parts)], dim=dim)
 
 
 class EngineOps:
@@ -133,6 +120,9 @@ class EngineOps:
 
     def attn_qk(self, q, k, v_tok, scale):
         return self.E.vae_attn_qk(q, k, v_tok, scale)
+
+    def tanh(self, x):
+        return self.E.tanh(x)
 
 
 def estimate_group_norm_sp(steps: Sequence, zs: torch.Tensor, comm: BandComm, ops, fuse_pre_gn: bool = True
@@ -212,5 +202,5 @@ def estimate_group_norm_sp(steps: Sequence, zs: torch.Tensor, comm: BandComm, op
             x = ops.conv(a.proj, oe, residual=res.pop())
             halo_ok = False
         elif s.kind == "tanh":
-            x = torch.tanh(x)
+            x = ops.tanh(x)
     return frozen

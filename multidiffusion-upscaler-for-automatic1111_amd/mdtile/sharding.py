@@ -89,11 +89,12 @@ def exchange_and_sum(partial: torch.Tensor, bands: Sequence[Band], rank: int, gr
     halos = halo_rows(bands, rank)
     if not halos:
         return partial
-    if _CTX is not None and partial.is_cuda and group is None:
+    if _use_ctx(partial, group):
         return exchange_and_sum_ctx(partial, bands)      # C ABI: pack -> ncclSend / ncclRecv -> k_halo_add
     # torch.distributed path (CPU tests over gloo, single-GPU multi-process checks).  RCCL ("nccl") moves device memory directly; a backend that cannot (gloo: CPU tests, single-GPU multi-process checks)
     # gets the slabs staged through the host
-    staged = partial.is_cuda and dist.get_backend(group) == "gloo"
+    staged = _staged(partial, group)
+    group = _grp(group)
     send = {peer: partial[:, :, lo:hi, :].contiguous() for peer, lo, hi in halos}
     if staged:
         send = {peer: t.cpu() for peer, t in send.items()}
@@ -138,7 +139,7 @@ def tiles_of_rank(num_tiles: int, rank: int, world: int) -> List[int]:
 def allreduce_stats(sum_mean_px: torch.Tensor, sum_var_px: torch.Tensor, px: torch.Tensor, group=None):
     """Slow-mode GroupNorm barrier across ranks: all-reduce(sum) of [sum_i px_i*mean_i, sum_i px_i*var_i, sum_i px_i]."""
     buf = torch.cat([sum_mean_px.flatten(), sum_var_px.flatten(), px.flatten()])
-    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    buf = comm_allreduce_sum(buf, group)
     n = sum_mean_px.numel()
     total = buf[2 * n]
     return (buf[n:2 * n] / total).view_as(sum_var_px), (buf[:n] / total).view_as(sum_mean_px)
@@ -146,10 +147,113 @@ def allreduce_stats(sum_mean_px: torch.Tensor, sum_var_px: torch.Tensor, px: tor
 
 # ---------------------------------------------------------------------------------------------------------------------
 # C-ABI shard context (include/mdtile.h "Multi-GPU"): the halo exchange as pack -> grouped ncclSend / ncclRecv -> fixed-order
-# k_halo_add, three launches per evaluation instead of the eager slab arithmetic of exchange_and_sum above.
+# k_halo_add, three launches per evaluation instead of the eager slab arithmetic of exchange_and_sum above; and the generic
+# collectives of the VAE side (row halos, statistics all-reduce, K / V all-gather, image gather) on the same communicator.
 # ---------------------------------------------------------------------------------------------------------------------
 _CTX = None          # mdtile.Shard of THIS process when it is one rank of a process-per-GPU job
 _CTX_SCRATCH = {}
+_DATA_GROUP = None   # torch.distributed group of the data plane when there is no C-ABI context (None = the default group)
+
+
+def process_context():
+    return _CTX
+
+
+def set_data_group(group) -> None:
+    """The torch.distributed group that carries tensors when the job has no C-ABI context: e.g. ONE "nccl" group next to a gloo
+    default group that only does control traffic (bench.py)."""
+    global _DATA_GROUP
+    _DATA_GROUP = group
+
+
+def _grp(group):
+    return group if group is not None else _DATA_GROUP
+
+
+def _use_ctx(t: torch.Tensor, group) -> bool:
+    return _CTX is not None and group is None and t.is_cuda
+
+
+def _staged(t: torch.Tensor, group) -> bool:
+    """torch.distributed path with a backend that cannot move device memory (gloo): go through the host."""
+    return t.is_cuda and dist.get_backend(_grp(group)) == "gloo"
+
+
+def comm_p2p(ops, group=None) -> None:
+    """Grouped point-to-point of this rank: ops = [(peer, tensor to send or None, tensor to receive into or None)], contiguous.
+    C-ABI context (one ncclGroup on torch's current stream) when active, torch.distributed batch_isend_irecv otherwise."""
+    ops = [o for o in ops if o[1] is not None or o[2] is not None]
+    if not ops:
+        return
+    probe = next(t for o in ops for t in o[1:] if t is not None)
+    if _use_ctx(probe, group):
+        _CTX.p2p([ops], streams=[torch.cuda.current_stream(probe.device).cuda_stream])
+        return
+    staged = _staged(probe, group)
+    group = _grp(group)
+    reqs, back = [], []
+    for peer, snd, rcv in ops:
+        if snd is not None:
+            reqs.append(dist.P2POp(dist.isend, snd.cpu() if staged else snd, peer, group=group))
+        if rcv is not None:
+            h = torch.empty(rcv.shape, dtype=rcv.dtype) if staged else rcv
+            reqs.append(dist.P2POp(dist.irecv, h, peer, group=group))
+            if staged:
+                back.append((rcv, h))
+    for r in dist.batch_isend_irecv(reqs):
+        r.wait()
+    for rcv, h in back:
+        rcv.copy_(h)
+
+
+def comm_allreduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
+    """All-reduce(sum) in place (returns t).  The C-ABI context reduces fp64; other dtypes are widened for the trip."""
+    if _use_ctx(t, group):
+        d = t if (t.dtype == torch.float64 and t.is_contiguous()) else t.double().contiguous()
+        _CTX.allreduce_stats([d], streams=[torch.cuda.current_stream(t.device).cuda_stream])
+        if d is not t:
+            t.copy_(d)
+        return t
+    if _staged(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=_grp(group))
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_grp(group))
+    return t
+
+
+def comm_allgather(t: torch.Tensor, world: int, group=None) -> List[torch.Tensor]:
+    """Every rank's `t` (one common shape), in rank order."""
+    t = t.contiguous()
+    if _use_ctx(t, group):
+        return list(_CTX.allgather([t], streams=[torch.cuda.current_stream(t.device).cuda_stream])[0].unbind(0))
+    src = t.cpu() if _staged(t, group) else t
+    parts = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(parts, src, group=_grp(group))
+    return [p.to(t.device) if p.device != t.device else p for p in parts]
+
+
+def gather_tiles_to_root(result: torch.Tensor, out_bboxes: Sequence[Sequence[int]], owner_of, rank: int, root: int = 0, group=None) -> torch.Tensor:
+    """VAE output tiles are disjoint rectangles of the result canvas, each decoded by one rank (`owner_of(i)`).  Every foreign
+    rectangle travels to `root` in ONE grouped exchange (each pair of GPUs has its own xGMI link, so the sends of different
+    owners run concurrently) and is pasted into root's canvas -- the single tensor upstream's vae_tile_forward returns
+    (scripts/tilevae.py:630-656)."""
+    ops, paste = [], []
+    for i, (x1, x2, y1, y2) in enumerate(out_bboxes):
+        own = owner_of(i)
+        if own == root:
+            continue
+        if rank == own:
+            ops.append((root, result[:, :, y1:y2, x1:x2].contiguous(), None))
+        elif rank == root:
+            buf = torch.empty((result.shape[0], result.shape[1], y2 - y1, x2 - x1), dtype=result.dtype, device=result.device)
+            ops.append((own, None, buf))
+            paste.append(((x1, x2, y1, y2), buf))
+    comm_p2p(ops, group)
+    for (x1, x2, y1, y2), buf in paste:
+        result[:, :, y1:y2, x1:x2].copy_(buf)
+    return result
 
 
 def init_process_context(rank: int, world: int, device: int, group=None):
@@ -163,59 +267,104 @@ def init_process_context(rank: int, world: int, device: int, group=None):
     return _CTX
 
 
-def init_process_context_checked(rank: int, world: int, device: int, timeout_s: float = 120.0, group=None) -> bool:
-    """init_process_context with a seat belt for its first contact with a given node: the communicator is created in a worker
-    thread (a rendezvous that never completes must not hang the job), then a small halo exchange through the C ABI is compared
-    with the same exchange over torch.distributed point-to-point.  Every rank reports; unless ALL succeeded the context is
-    dropped everywhere and exchange_and_sum keeps using torch.distributed.  Returns whether the C-ABI path is active."""
-    global _CTX
-    import sys
+def _run_with_timeout(fn, timeout_s: float, device=None):
+    """fn() in a worker thread.  Returns (value, error text or None).  A call that does not return in time is abandoned: a
+    result that arrives late is destroyed by the worker itself and never reaches the caller."""
     import threading
-    err: List[BaseException] = []
+    box = {"abandoned": False}
 
-    def _init():
+    def _work():
         try:
-            if torch.cuda.is_available():
-                torch.cuda.set_device(device)      # the current device is per thread; the id broadcast below runs on it
-            init_process_context(rank, world, device, group)
-        except BaseException as e:     # noqa: BLE001 -- reported below, the job continues on the torch.distributed path
-            err.append(e)
+            if device is not None and torch.cuda.is_available():
+                torch.cuda.set_device(device)       # the current device is per thread
+            v = fn()
+            if box["abandoned"] and hasattr(v, "destroy"):
+                v.destroy()
+            else:
+                box["value"] = v
+        except BaseException as e:      # noqa: BLE001 -- reported to the caller, the job continues on the fallback path
+            box["error"] = e
 
-    t = threading.Thread(target=_init, daemon=True)
+    t = threading.Thread(target=_work, daemon=True)
     t.start()
     t.join(timeout_s)
-    ok = not t.is_alive() and not err and _CTX is not None
-    why = "timed out" if t.is_alive() else (repr(err[0]) if err else "")
+    if t.is_alive():
+        box["abandoned"] = True
+        return None, "timed out"
+    if "error" in box:
+        return None, repr(box["error"])
+    return box.get("value"), None
+
+
+def _vote(ok: bool, dev, group) -> bool:
+    """All ranks agree (control group: a host tensor on gloo, a device tensor on an RCCL-backed group)."""
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if dist.get_backend(group) == "gloo" else dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return int(flag.item()) == 1
+
+
+def init_process_context_checked(rank: int, world: int, device: int, timeout_s: float = 120.0, group=None) -> bool:
+    """init_process_context with a seat belt for its first contact with a given node.  Every collective of the CONTROL group
+    (`group`, torch.distributed) is issued from the main thread, in the same order on every rank:
+      1. rank 0 draws the RCCL id (a failure travels as a sentinel) and broadcasts it;
+      2. ONLY ncclCommInitRank runs in a worker thread (a rendezvous that never completes must not hang the job); vote;
+      3. the engine's own bring-up check (mdtile_shard_selfcheck: all-reduce, broadcast, ring send / receive, all-gather) and a halo
+         exchange compared with the same exchange over torch.distributed, again under a timeout; vote;
+    The context becomes visible (module global, main thread) only after every rank voted yes twice; a communicator that arrives
+    late is destroyed, never used.  Returns whether the C-ABI path is active; otherwise the job stays on torch.distributed."""
+    global _CTX
+    import sys
+    import mdtile
     dev = torch.device("cuda", device) if torch.cuda.is_available() else torch.device("cpu")   # (cpu: the gloo tests of this logic)
-    if ok:
+    box = [None]
+    if rank == 0:
         try:
-            rows = 8 * world
-            bands = [Band(r, r, r + 1, r, r + 1, max(0, 8 * r - 2), min(rows, 8 * r + 10), 8 * r, 8 * r + 8) for r in range(world)]
-            g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-            a = torch.randn(2, 4, rows, 64, generator=g).to(dev)
-            b = a.clone()
-            exchange_and_sum_ctx(a, bands)
-            ctx, _CTX = _CTX, None
-            try:
-                exchange_and_sum(b, bands, rank, group)
-            finally:
-                _CTX = ctx
-            lo, hi = bands[rank].row_lo, bands[rank].row_hi
+            box[0] = mdtile.Shard.unique_id()
+        except BaseException as e:      # noqa: BLE001
+            box[0] = ("error", repr(e))
+    dist.broadcast_object_list(box, src=0, group=group)
+    ctx, why = None, None
+    if isinstance(box[0], (bytes, bytearray)):
+        ctx, why = _run_with_timeout(lambda: mdtile.Shard(nranks=world, rank=rank, uid=bytes(box[0]), device=device), timeout_s, device)
+    else:
+        why = f"rank 0 could not draw an RCCL id: {box[0][1] if box[0] else 'no id'}"
+    ok = _vote(ctx is not None, dev, group)
+    if ok:
+        rows = 8 * world
+        bands = [Band(r, r, r + 1, r, r + 1, max(0, 8 * r - 2), min(rows, 8 * r + 10), 8 * r, 8 * r + 8) for r in range(world)]
+
+        def _payload():
+            return torch.randn(2, 4, rows, 64, generator=torch.Generator(device="cpu").manual_seed(1234 + rank)).to(dev)
+
+        def _check():
+            ctx.selfcheck()
+            a = _payload()
+            exchange_and_sum_ctx(a, bands, ctx)
             if dev.type == "cuda":
                 torch.cuda.synchronize(dev)
+            return a
+        a, why = _run_with_timeout(_check, timeout_s, device)
+        # the reference exchange is a collective of the control group: EVERY rank runs it, whatever its own check said
+        b = exchange_and_sum(_payload(), bands, rank, group)        # torch.distributed path: the context is not installed yet
+        good = a is not None
+        if good:
+            lo, hi = bands[rank].row_lo, bands[rank].row_hi
             if not torch.equal(a[:, :, lo:hi], b[:, :, lo:hi]):
-                ok, why = False, "halo self-check mismatch against torch.distributed"
-        except BaseException as e:     # noqa: BLE001
-            ok, why = False, repr(e)
-    flag = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    if not ok:
-        print(f"[mdtile] rank {rank}: C-ABI shard context unavailable ({why}); halo exchange stays on torch.distributed", file=sys.stderr)
-    if int(flag.item()) == 0:
-        _CTX = None
-        _CTX_SCRATCH.clear()
-        return False
-    return True
+                good, why = False, "halo self-check mismatch against torch.distributed"
+        ok = _vote(good, dev, group)
+    if why:
+        print(f"[mdtile] rank {rank}: C-ABI shard context unavailable ({why}); collectives stay on torch.distributed", file=sys.stderr)
+    _CTX_SCRATCH.clear()
+    if ok:
+        _CTX = ctx
+        return True
+    _CTX = None
+    if ctx is not None:
+        try:
+            _run_with_timeout(ctx.destroy, 10.0, device)
+        except BaseException:   # noqa: BLE001
+            pass
+    return False
 
 
 def band_rows_table(bands: Sequence[Band]) -> List[int]:

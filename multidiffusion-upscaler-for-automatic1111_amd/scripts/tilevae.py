@@ -217,6 +217,9 @@ class VAEHook:
         self._program: Optional[List[Step]] = None
         self.last_seconds = None
         self.shard = (0, 1)   # (rank, world): process-per-GPU runs decode tiles rank, rank+world, ... (mdtile/sharding.py)
+        # process-per-GPU runs: the rank whose call returns the ASSEMBLED image, as upstream's single tensor (:630-656) -- the other
+        # ranks' tile rectangles travel to it in one grouped exchange; None leaves every rank with only its own tiles filled in
+        self.gather_to: Optional[int] = None
         # single-process multi-device decode (what a webui process can use): CUDA device indices, e.g. [0, 1, 2, 3]; the tiles are
         # dealt round-robin to the devices, each with its own copy of the packed weights; fast mode only (no collective needed:
         # the frozen statistics are computed once and copied).  A device may be listed twice (functional runs on one GPU).
@@ -238,10 +241,9 @@ class VAEHook:
 
     # ---- geometry (host ints via the C ABI) -------------------------------------------------------------------------
     def get_best_tile_size(self, lowerbound, upperbound):
-        """Upstream keeps this helper on the hook (:390-403); here the whole split lives behind the C ABI
-        (mdtile_vae_split_tiles), so the name only forwards to it: the real tile size of a [lowerbound, upperbound] search is
-        the width of the first tile of such a split."""
-        raise NotImplementedError("tile sizes are chosen inside mdtile_vae_split_tiles; use VAEHook.split_tiles")
+        """Upstream's helper (:390-403): the smallest multiple of 32 / 16 / 8 / 4 / 2 above `lowerbound` that still fits under
+        `upperbound`.  The split itself lives behind the C ABI (mdtile_vae_split_tiles uses the same function)."""
+        return self.engine.vae_best_tile_size(lowerbound, upperbound)
 
     def split_tiles(self, h, w):
         return self.engine.vae_split_tiles(h, w, self.tile_size, self.is_decoder)
@@ -254,8 +256,7 @@ class VAEHook:
             self._program_dev = dev
         return self._program
 
-    @staticmethod
-    def _run_until_norm(steps: List[Step], st: TileState):
+    def _run_until_norm(self, steps: List[Step], st: TileState):
         """Advance one tile to its next GroupNorm (exclusive) or to the end."""
         while st.pc < len(steps):
             s = steps[st.pc]
@@ -272,7 +273,7 @@ class VAEHook:
             elif s.kind == "attn":
                 st.x = s.attn(st.x, st.res.pop())
             elif s.kind == "tanh":
-                st.x = torch.tanh(st.x)
+                st.x = self.engine.tanh(st.x)
             st.pc += 1
 
     # ---- fast mode, every norm frozen: record-image hand-over between the 3x3 convs ----------------------------------
@@ -339,7 +340,7 @@ class VAEHook:
             elif s.kind == "attn":
                 x, xrec = s.attn(x, res.pop()), None
             elif s.kind == "tanh":
-                x = torch.tanh(x)
+                x = E.tanh(x)
         return x
 
     def _apply_norm(self, steps: List[Step], st: TileState, var: Tensor, mean: Tensor):
@@ -386,22 +387,20 @@ class VAEHook:
         return frozen
 
     def _pooled_across_ranks(self, gp: "GroupNormParam", steps, dev):
-        """Slow mode on several GPUs: all-reduce(sum) of [sum px*mean, sum px*var, sum px] (2*B*32+1 floats) per barrier."""
-        import torch.distributed as dist
+        """Slow mode on several GPUs: all-reduce(sum) of [sum px*mean, sum px*var, sum px] (2*B*32+1 floats) per barrier, on the
+        job's data plane (the engine's RCCL communicator when the process has one, mdtile/sharding.py)."""
         from mdtile import sharding
-        flag = torch.tensor([1.0 if gp.var_list else 0.0], device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        if flag.item() == 0.0:
-            return None
         BG = None
         if gp.var_list:
             px = torch.tensor(gp.pixel_list, dtype=torch.float32, device=dev).unsqueeze(1)
             sm, sv, sp = (torch.vstack(gp.mean_list) * px).sum(0), (torch.vstack(gp.var_list) * px).sum(0), px.sum().view(1)
             BG = sm.numel()
-        shape = torch.tensor([BG or 0], device=dev)
-        dist.all_reduce(shape, op=dist.ReduceOp.MAX)
+        # who still has tiles at this barrier, and how wide the statistics rows are (ranks without tiles contribute zeros)
+        head = sharding.comm_allreduce_sum(torch.tensor([1.0 if BG else 0.0, float(BG or 0)], dtype=torch.float64, device=dev))
+        if head[0].item() == 0.0:
+            return None
         if BG is None:
-            BG = int(shape.item())
+            BG = int(round(head[1].item() / head[0].item()))
             sm, sv, sp = torch.zeros(BG, device=dev), torch.zeros(BG, device=dev), torch.zeros(1, device=dev)
         return sharding.allreduce_stats(sm, sv, sp)
 
@@ -607,6 +606,13 @@ class VAEHook:
 
         if nan_flags and bool(torch.stack(nan_flags).any().item()):
             devices.test_for_nans(torch.full((1,), float("nan")), "vae")     # raises the host's NansException (or not: --disable-nan-check)
+        if world > 1 and self.gather_to is not None and not interrupted:
+            from mdtile import sharding
+            if result is None and rank == self.gather_to:
+                result = torch.zeros((N, 3 if self.is_decoder else 2 * int(getattr(net, "z_channels", 4)),
+                                      *((height * 8, width * 8) if self.is_decoder else (height // 8, width // 8))), device=dev, dtype=torch.float32)
+            if result is not None:
+                sharding.gather_tiles_to_root(result, out_bboxes, lambda i: i % world, rank, self.gather_to)
         self.last_seconds = time() - t0
         if interrupted and result is not None:
             return result.to(dtype)          # upstream hands back what is finished (:644-647)

@@ -90,7 +90,7 @@ def pool_stats(vars_: Sequence[torch.Tensor], means: Sequence[torch.Tensor], pix
     """tilevae.py:320-335 -- pixel-count weighted mean of per-tile means AND of per-tile variances (the between-tile
     spread of the means is ignored upstream; do not 'fix')."""
     px = torch.tensor(list(pixels), dtype=torch.float32) / max(pixels)
-    p = (px / px.sum()).unsqueeze(1)
+    p = (px / px.sum()).unsqueeze(1).to(vars_[0].device)      # (formed on the host like upstream; the device only when run via gpu_reference)
     return (torch.vstack(list(vars_)) * p).sum(0), (torch.vstack(list(means)) * p).sum(0)
 
 
@@ -250,5 +250,5 @@ def tiled_forward(net, z: torch.Tensor, tile_size: int, fast: bool, is_decoder: 
         if result is None:                                                  # tilevae.py:629-632
             result = torch.zeros((N, tile.shape[1], H * 8 if is_decoder else H // 8, W * 8 if is_decoder else W // 8))
         ob = outs[t]
-        result[:, :, ob[2]:ob[3], ob[0]:ob[1]] = crop_valid_region(tile, ins[t], ob, is_decoder)
+        result[:, :, ob[2]:ob[3], ob[0]:ob[1]] = crop_valid_region(tile, ins[t], ob, is_decoder).to(result.device)
     return result

@@ -79,7 +79,7 @@ def test_conv_rec_vs_torch(plugin, cuda, B, cin, cout, H, W, up, res):
     # fp32 + activated record output in one launch
     y, yrec = pc.call_rec(xrec, residual=rr, upsample2x=up, want_f32=True, want_rec=True, rec_coef=out_coef.to(cuda))
     err = _rel(y.cpu(), ref)
-    assert err < 1e-4, f"record conv fp32 output: rel err {err}"
+    assert err < 5e-5, f"record conv fp32 output: rel err {err}"
     got = yrec.to_f32().cpu()
     want = _act(ref, out_coef)
     assert _rel(got, want) < 2e-4, f"record conv activated record output: rel err {_rel(got, want)}"
@@ -93,7 +93,7 @@ def test_conv_rec_vs_torch(plugin, cuda, B, cin, cout, H, W, up, res):
     # raw record output only (what conv2 hands to upsample.conv), no fp32 copy
     y3, yrec3 = pc.call_rec(xrec, residual=rr, upsample2x=up, want_f32=False, want_rec=True)
     assert y3 is None
-    assert _rel(yrec3.to_f32().cpu(), ref) < 1e-4
+    assert _rel(yrec3.to_f32().cpu(), ref) < 5e-5
 
 
 @pytest.mark.parametrize("cin,cout,H,W,B", [(128, 3, 40, 70, 1), (128, 8, 17, 33, 2), (256, 16, 24, 40, 1)])
@@ -111,7 +111,7 @@ def test_conv_rec_narrow_output(plugin, cuda, cin, cout, H, W, B):
     assert pc.takes_rec()
     y, yr = pc.call_rec(E.rec_from_f32(x.to(cuda), coef.to(cuda)), want_f32=True)
     assert yr is None and y.shape == ref.shape
-    assert _rel(y.cpu(), ref) < 1e-4
+    assert _rel(y.cpu(), ref) < 5e-5
 
 
 def test_conv_rec_matches_fp32_handover_kernel(plugin, cuda):
@@ -146,9 +146,9 @@ def test_tiled_decode_record_path_vs_fp32_handover_and_oracle(plugin, cuda, fast
             outs[rec] = hook(z.to(cuda)).cpu()
     finally:
         plugin.tilevae.REC_PATH = old
-    assert _rel(outs[True], ref) < 1e-3
-    assert _rel(outs[False], ref) < 1e-3
-    assert _rel(outs[True], outs[False]) < 1e-4
+    assert _rel(outs[True], ref) < 2e-4
+    assert _rel(outs[False], ref) < 2e-4
+    assert _rel(outs[True], outs[False]) < 5e-5
 
 
 def test_tiled_encode_record_path(plugin, cuda):
@@ -161,4 +161,4 @@ def test_tiled_encode_record_path(plugin, cuda):
     enc.original_forward = enc.forward
     hook = plugin.tilevae.VAEHook(enc, 64, is_decoder=False, fast_decoder=False, fast_encoder=True, color_fix=False)
     out = hook(x.to(cuda)).cpu()
-    assert _rel(out, ref) < 1e-3
+    assert _rel(out, ref) < 2e-4

@@ -44,7 +44,7 @@ def test_attention_band_queries_all_keys(plugin, cuda, B, C, Tq, Tk):
     ref = torch.bmm(w, v).permute(0, 2, 1)
     out = E.vae_attn_qk(q.to(cuda), k.to(cuda), v.to(cuda), scale).cpu()
     err = (out - ref).abs().max().item() / ref.abs().max().item()
-    assert err < 1e-4, f"band attention rel err {err}"
+    assert err < 5e-5, f"band attention rel err {err}"
 
 
 def _free_port() -> int:

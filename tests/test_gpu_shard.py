@@ -162,3 +162,108 @@ def test_process_context_bringup_agrees_and_exchanges(plugin, cuda):
     assert all(r[3] == "" for r in res), res
     assert res[0][1] == res[1][1], f"ranks disagree about the transport: {res}"
     assert all(r[2] for r in res), res
+
+
+# ---- RCCL itself, on the hardware at hand: a ONE-rank communicator through the product path ----------------------------------
+def test_rccl_one_rank_communicator_process_form(plugin, cuda):
+    """mdtile_shard_unique_id -> mdtile_shard_init_rank(nranks = 1): dlopen of librccl, the symbol table, ncclCommInitRank, then every
+    collective the engine issues (ncclAllReduce, ncclBroadcast, a grouped self ncclSend / ncclRecv, ncclAllGather) on torch's stream."""
+    E = plugin.engine
+    sh = E.Shard(nranks=1, rank=0, uid=E.Shard.unique_id(), device=0)
+    assert (sh.nranks, sh.nlocal, sh.first, sh.rccl) == (1, 1, 0, True)
+    sh.selfcheck()                                                   # the engine's own bring-up check (context streams)
+    cur = [torch.cuda.current_stream().cuda_stream]
+    d = torch.arange(8, dtype=torch.float64, device=cuda) * 0.5
+    want = d.clone()
+    sh.allreduce_stats([d], streams=cur)
+    b = torch.randn(1000, device=cuda)
+    bw = b.clone()
+    sh.bcast([b], 0, streams=cur)
+    snd = torch.randn(3, 4096, device=cuda)
+    rcv = torch.zeros_like(snd)
+    sh.p2p([[(0, snd, rcv)]], streams=cur)                            # grouped self send / receive
+    g = sh.allgather([snd], streams=cur)[0]
+    torch.cuda.synchronize()
+    assert torch.equal(d, want) and torch.equal(b, bw) and torch.equal(rcv, snd) and torch.equal(g[0], snd)
+    sh.destroy()
+
+
+def test_rccl_one_rank_communicator_single_process_form(plugin, cuda, monkeypatch):
+    """mdtile_shard_init(1, {0}) with MDTILE_SHARD_TRANSPORT=rccl: ncclCommInitAll on one device (a one-device context normally
+    needs no transport and takes the copy path)."""
+    E = plugin.engine
+    monkeypatch.setenv("MDTILE_SHARD_TRANSPORT", "rccl")
+    sh = E.Shard(dev_ids=[0])
+    assert (sh.nranks, sh.nlocal, sh.rccl) == (1, 1, True)
+    sh.selfcheck()
+    sh.destroy()
+    monkeypatch.delenv("MDTILE_SHARD_TRANSPORT")
+    assert E.Shard(dev_ids=[0]).rccl is False
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_selfcheck_p2p_allgather_copy_transport(plugin, cuda, world):
+    """The same bring-up check and the generic collectives on the copy transport (one GPU listed `world` times)."""
+    E = plugin.engine
+    sh = E.Shard(dev_ids=[0] * world)
+    assert sh.rccl is False
+    sh.selfcheck()
+    torch.manual_seed(world)
+    cur = [torch.cuda.current_stream().cuda_stream] * world
+    # every rank sends a distinct row to every other rank; the k-th send to a peer pairs with the peer's k-th receive from me
+    payload = [[torch.randn(257, device=cuda) for _ in range(world)] for _ in range(world)]       # payload[src][dst]
+    inbox = [[torch.zeros(257, device=cuda) for _ in range(world)] for _ in range(world)]         # inbox[dst][src]
+    ops = [[(q, payload[r][q], inbox[r][q]) for q in range(world) if q != r] for r in range(world)]
+    if world > 1:
+        sh.p2p(ops, streams=cur)
+    parts = sh.allgather([payload[r][r] for r in range(world)], streams=cur)
+    torch.cuda.synchronize()
+    for r in range(world):
+        for q in range(world):
+            if q != r:
+                assert torch.equal(inbox[r][q], payload[q][r])
+            assert torch.equal(parts[r][q], payload[q][q])
+
+
+def _ctx1_worker(port, q):
+    import os
+    import sys
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "multidiffusion-upscaler-for-automatic1111_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        from mdtile import sharding
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        active = sharding.init_process_context_checked(0, 1, 0, timeout_s=120.0)
+        ctx = sharding.process_context()
+        t = torch.arange(6, dtype=torch.float32, device=dev)
+        r = sharding.comm_allreduce_sum(t.clone())
+        parts = sharding.comm_allgather(t, 1)
+        snd, rcv = t.clone(), torch.zeros_like(t)
+        sharding.comm_p2p([(0, snd, rcv)])
+        torch.cuda.synchronize()
+        ok = torch.equal(r, t) and torch.equal(parts[0], t) and torch.equal(rcv, snd)
+        q.put((bool(active), ctx is not None and ctx.rccl, bool(ok), ""))
+        dist.destroy_process_group()
+    except BaseException as e:  # noqa: BLE001
+        q.put((None, None, False, repr(e)))
+
+
+def test_process_context_bringup_one_rank_uses_rccl(plugin, cuda):
+    """bench.py's N > 1 bring-up (gloo control group + the engine's own RCCL communicator for the data plane) with world = 1:
+    the checked bring-up must END on the C-ABI context and the data-plane helpers must run on it."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_ctx1_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=300)
+    p.join(60)
+    assert res[3] == "", res
+    assert res[0] is True and res[1] is True and res[2] is True, res

@@ -109,7 +109,7 @@ def test_conv2d_vs_torch(plugin, cuda, B, cin, cout, k, H, W, up, res, tok, exac
     err = _rel(out, ref)
     # exact-fp32 MFMA kernel: fp32 round-off only.  Default path (3x3, cin % 16 == 0): split-bf16 operands, 16 significand
     # bits per factor, fp32 accumulation -> <= 1e-4 of the output range (the end-to-end budget is 1e-3).
-    tol = 2e-5 if exact else 1e-4
+    tol = 2e-5 if exact else 5e-5
     assert err < tol, f"conv rel err {err}; worst at {np.unravel_index((out - ref).abs().argmax().item(), ref.shape)}"
 
 
@@ -144,7 +144,7 @@ def test_conv2d_fused_groupnorm_silu(plugin, cuda, B, cin, cout, H, W, res):
     coef = E.gn_coeffs(mean.to(cuda), var.to(cuda), gamma.to(cuda), beta.to(cuda), cin, 32, 1e-6)
     out = pc(x.to(cuda), residual=None if r is None else r.to(cuda), pre_gn=coef).cpu()
     err = _rel(out, ref)
-    assert err < 1e-4, f"fused GN+SiLU conv rel err {err}"
+    assert err < 5e-5, f"fused GN+SiLU conv rel err {err}"
     # and identical (to fp32 round-off of exp / rcp) to the engine's own unfused pair
     xa = E.gn_apply(x.to(cuda), mean.to(cuda), var.to(cuda), gamma.to(cuda), beta.to(cuda), 32, 1e-6, True)
     out2 = pc(xa, residual=None if r is None else r.to(cuda)).cpu()
@@ -183,7 +183,7 @@ def test_attention_vs_oracle(plugin, cuda, B, C, T, exact):
     out = E.vae_attn(q.to(cuda), k.to(cuda), v.permute(0, 2, 1).contiguous().to(cuda), scale, exact=exact).cpu()
     err = _rel(out, ref)
     # exact: fp32 MFMA.  Default: split-bf16 operands (16 significand bits per factor), fp32 accumulation + softmax.
-    assert err < (2e-5 if exact else 1e-4), f"attention rel err {err}"
+    assert err < (2e-5 if exact else 5e-5), f"attention rel err {err}"
 
 
 @pytest.mark.parametrize("exact", [False, True], ids=["bf16x3", "f32"])
@@ -200,7 +200,7 @@ def test_attention_online_softmax_rescale_branch(plugin, cuda, exact):
     w_ = torch.softmax(torch.bmm(q.permute(0, 2, 1), k) * scale, dim=2)
     ref = torch.bmm(v, w_.permute(0, 2, 1))
     out = E.vae_attn(q.to(cuda), k.to(cuda), v.permute(0, 2, 1).contiguous().to(cuda), scale, exact=exact).cpu()
-    assert _rel(out, ref) < (2e-5 if exact else 1e-4)
+    assert _rel(out, ref) < (2e-5 if exact else 5e-5)
 
 
 def test_attn_block_golden(plugin, cuda, golden_vae):
@@ -213,7 +213,7 @@ def test_attn_block_golden(plugin, cuda, golden_vae):
         ref = vo.attn_body(ab, hx)
     pack = plugin.tilevae.AttnPack(ab.to(cuda))
     out = pack(hx.to(cuda), torch.zeros_like(hx).to(cuda)).cpu()
-    assert _rel(out, ref) < 1e-4
+    assert _rel(out, ref) < 5e-5
 
 
 def test_crop_store_and_fast_input(plugin, cuda):
@@ -247,7 +247,7 @@ def test_tiled_decode_vs_goldens_and_oracle(plugin, cuda, cases, golden_vae):
         out = hook(z.to(cuda)).cpu()
         gold = torch.from_numpy(golden_vae[c["name"] + "/sub"])
         err = (out[:, :, ::s, ::s] - gold).abs().max().item() / gold.abs().max().item()
-        assert err < 1e-3, f"{c['name']}: rel err {err}"
+        assert err < 2e-4, f"{c['name']}: rel err {err}"
         mom = golden_vae[c["name"] + "/moments"]
         assert abs(out.double().sum().item() - mom[0]) < 1e-3 * max(1.0, abs(mom[0]), (mom[1]) ** 0.5)
         assert abs((out.double() ** 2).sum().item() - mom[1]) < 2e-3 * mom[1]
@@ -265,7 +265,7 @@ def test_tiled_decode_full_width_decoder(plugin, cuda, fast):
     hook = plugin.tilevae.VAEHook(dec, 12, is_decoder=True, fast_decoder=fast, fast_encoder=False, color_fix=False)
     out = hook(z.to(cuda)).cpu()
     err = _rel(out, ref)
-    assert err < 1e-3, f"full-width tiled decode (fast={fast}): rel err {err}"
+    assert err < 2e-4, f"full-width tiled decode (fast={fast}): rel err {err}"
 
 
 def test_untiled_small_input_takes_original_forward(plugin, cuda):
@@ -321,7 +321,7 @@ def test_tiled_encode_vs_goldens_and_oracle(plugin, cuda):
         g = torch.from_numpy(gold[c["name"] + "/out"])
         assert out.shape == g.shape, f"{c['name']}: shape {tuple(out.shape)} vs upstream {tuple(g.shape)}"
         err = _rel(out, g)
-        assert err < 1e-3, f"{c['name']}: rel err vs the upstream golden {err}"
+        assert err < 2e-4, f"{c['name']}: rel err vs the upstream golden {err}"
 
 
 @pytest.mark.parametrize("fast,color_fix", [(True, False), (False, False), (True, True)])
@@ -337,7 +337,7 @@ def test_tiled_encode_full_width_encoder(plugin, cuda, fast, color_fix):
     out = hook(x.to(cuda)).cpu()
     assert out.shape == ref.shape
     err = _rel(out, ref)
-    assert err < 1e-3, f"full-width tiled encode (fast={fast}, color_fix={color_fix}): rel err {err}"
+    assert err < 2e-4, f"full-width tiled encode (fast={fast}, color_fix={color_fix}): rel err {err}"
 
 
 @pytest.mark.parametrize("fast", [True, False])
@@ -352,7 +352,7 @@ def test_tiled_decode_batch_of_two(plugin, cuda, fast):
     hook = plugin.tilevae.VAEHook(dec, 16, is_decoder=True, fast_decoder=fast, fast_encoder=False, color_fix=False)
     out = hook(z.to(cuda)).cpu()
     assert out.shape == ref.shape
-    assert _rel(out, ref) < 1e-3
+    assert _rel(out, ref) < 2e-4
 
 
 def test_tiled_decode_half_precision_vae(plugin, cuda):

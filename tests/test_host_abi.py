@@ -65,6 +65,24 @@ def test_vae_split_tiles_matches_upstream(built_lib, cases):
         assert ins == t["ins"] and outs == t["outs"], t["args"]
 
 
+def test_best_tile_size_matches_upstream(built_lib):
+    """VAEHook.get_best_tile_size (upstream scripts/tilevae.py:390-403) through the C ABI, over the whole range split_tiles can ask for."""
+    from oracle import stub_host as sh, vae_oracle as vo
+    pl = sh.load_plugin()
+    hook = pl.tilevae.VAEHook(None, 256, is_decoder=True, fast_decoder=True, fast_encoder=True, color_fix=False)
+    ref_hook = None
+    if sh.reference_available():
+        ref_hook = sh.load_reference().tilevae.VAEHook(None, 256, is_decoder=True, fast_decoder=True, fast_encoder=True, color_fix=False)
+    for upper in (48, 64, 96, 250, 256, 512, 3072):
+        for lower in list(range(1, 70)) + [upper - 33, upper - 31, upper - 1, upper, upper + 5]:
+            if lower < 1:
+                continue
+            got = hook.get_best_tile_size(lower, upper)
+            assert got == vo.best_tile_size(lower, upper), (lower, upper)
+            if ref_hook is not None:
+                assert got == ref_hook.get_best_tile_size(lower, upper), (lower, upper)
+
+
 def test_no_cpu_fallback(built_lib):
     x = torch.zeros(1, 4, 16, 16)
     with pytest.raises(built_lib.MdtileError, match="no CPU fallback"):

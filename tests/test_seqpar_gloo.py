@@ -42,6 +42,9 @@ class TorchOps:
             y = y.permute(0, 2, 3, 1).reshape(B, H * W, C).contiguous()
         return y
 
+    def tanh(self, x):
+        return torch.tanh(x)
+
     def gn_sums(self, x, row_lo, row_hi):
         B, C = x.shape[:2]
         v = x[:, :, row_lo:row_hi, :].double().reshape(B * 32, -1)

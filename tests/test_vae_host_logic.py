@@ -75,9 +75,13 @@ def _worker(rank, world, port, fast, q):
         z = torch.randn(1, 4, 40, 56)
         hook = _hook(dec, 16, True, fast)
         hook.shard = (rank, world)
+        hook.gather_to = 0          # rank 0 returns the assembled image (one grouped exchange of the tile rectangles)
         with torch.no_grad():
             out = hook(z)
             ref = vo.tiled_forward(ld.make_decoder(0, small=True), z, 16, fast)
+        if rank == 0:
+            err = (out - ref).abs().max().item() / ref.abs().max().item()
+            assert err < 2e-4, f"assembled image on rank 0: rel err {err}"
         ins, outs = vo.split_tiles(40, 56, 16, True)
         mine = list(range(rank, len(ins), world))
         assert mine, "test geometry must give every rank a tile"

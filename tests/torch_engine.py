@@ -57,6 +57,12 @@ class TorchEngine:
     def vae_fast_input(self, z, tile_size):
         return vo.fast_mode_input(z, tile_size)
 
+    def vae_best_tile_size(self, lowerbound, upperbound):
+        return vo.best_tile_size(lowerbound, upperbound)
+
+    def tanh(self, x, out=None):
+        return torch.tanh(x)
+
     def gather_rect(self, z, x, y, w, h):
         return z[:, :, y:y + h, x:x + w].clone()
 
@@ -122,3 +128,6 @@ class TorchSeqParOps:
 
     def attn_qk(self, q, k, v_tok, scale):
         return TorchEngine().vae_attn(q, k, v_tok, scale)
+
+    def tanh(self, x):
+        return torch.tanh(x)

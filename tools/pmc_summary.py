@@ -7,6 +7,30 @@ half of the bytes of wide coalesced reads (TCC_EA0_RDREQ x 64 B against 128-B re
 import collections, csv, glob, gzip, json, os, sys
 
 
+XCDS = 8
+
+
+def load_clock(d):
+    """GRBM_GUI_ACTIVE (summed over the 8 XCDs) / kernel duration of the same dispatch -> GHz per kernel, when the pass collected it."""
+    agg = collections.defaultdict(lambda: [0.0, 0.0])
+    for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv*"), recursive=True):
+        op = gzip.open if fn.endswith(".gz") else open
+        with op(fn, "rt") as f:
+            for r in csv.DictReader(f):
+                if r["Counter_Name"] != "GRBM_GUI_ACTIVE" or not r.get("End_Timestamp"):
+                    continue
+                a = agg[r["Kernel_Name"]]
+                a[0] += float(r["Counter_Value"]) / XCDS
+                a[1] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    return {k: v[0] / v[1] for k, v in agg.items() if v[1] > 0}
+
+
+def libmdtile_digest():
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stamp = os.path.join(here, "multidiffusion-upscaler-for-automatic1111_amd", "mdtile", ".libmdtile.stamp")
+    return open(stamp).read().strip() if os.path.exists(stamp) else ""
+
+
 def load(d, counter):
     agg = collections.defaultdict(lambda: [0.0, set()])
     files = glob.glob(os.path.join(d, "**", "*counter_collection.csv*"), recursive=True)
@@ -25,6 +49,7 @@ def load(d, counter):
 def main():
     fetch_dir, write_dir, out = sys.argv[1:4]
     fe, wr = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
+    clk = load_clock(fetch_dir)
     kernels = {}
     for k in sorted(set(fe) | set(wr), key=lambda k: -(fe.get(k, [0])[0] * 2 + wr.get(k, [0])[0])):
         nf = len(fe[k][1]) if k in fe else 0
@@ -34,8 +59,11 @@ def main():
         w_kb = wr[k][0] / max(nw, 1) if k in wr else 0.0
         kernels[k[:160]] = {"dispatches": n, "fetch_KB_raw_per_launch": round(f_kb, 1), "write_KB_per_launch": round(w_kb, 1),
                             "hbm_bytes_per_launch": int((2.0 * f_kb + w_kb) * 1024)}
+        if k in clk:
+            kernels[k[:160]]["clock_GHz"] = round(clk[k], 4)
     with open(out, "w") as f:
-        json.dump({"note": "HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KB, separate rocprofv3 --pmc passes", "kernels": kernels}, f, indent=1)
+        json.dump({"note": "HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KB, separate rocprofv3 --pmc passes; clock_GHz = GRBM_GUI_ACTIVE / 8 XCDs / "
+                           "kernel duration in the FETCH_SIZE pass", "libmdtile_digest": libmdtile_digest(), "kernels": kernels}, f, indent=1)
     for k, v in list(kernels.items())[:12]:
         print(f"{k[:80]:80s} n={v['dispatches']:5d}  {v['hbm_bytes_per_launch'] / 1e6:10.1f} MB/launch")
 
