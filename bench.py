@@ -245,6 +245,24 @@ def main():
             t_vae = time.perf_counter() - tv
     finally:
         builtins.print = _print
+    debug_check = None
+    if world > 1 and args.debug_single_device and hook is not None:
+        # functional check of the N-rank flow (all ranks share cuda:0): rank 0's ASSEMBLED image (sequence-parallel estimator, tiles
+        # dealt to the ranks, rectangles gathered) against the plain single-rank decode of the same latent on the same device
+        img = hook(z)
+        sync_all()
+        if rank == 0:
+            solo = pl.tilevae.VAEHook(dec, args.vae_tile, is_decoder=True, fast_decoder=not args.slow_vae, fast_encoder=False, color_fix=False)
+            builtins.print = lambda *a, **k: None
+            try:
+                ref = solo(z)
+            finally:
+                builtins.print = _print
+            debug_check = {"assembled_image_rel_err_vs_single_rank": float((img.float() - ref.float()).abs().max().item() / ref.float().abs().max().item()),
+                           "image_shape": list(img.shape)}
+            del ref
+        del img
+        sync_all()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64)        # control plane (gloo)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -541,7 +559,7 @@ def main():
             "value_f32": None if value_f32 is None else round(value_f32, 1), "ms_per_step_f32": None if ms_f32 is None else round(ms_f32, 2),
             "parity": parity,
             "roofline": roofline, "roofline_blend": roofline_blend, "roofline_blend_f16": roofline_blend_f16, "cpu_baseline": cpu_baseline,
-            "transport": transport,
+            "transport": transport, "debug_check": debug_check,
         }
         print(json.dumps(out))
     if world > 1:

@@ -22,6 +22,8 @@ for w in $WHAT; do
     rccl) cd /tmp   # RCCL kernels of the 1-rank communicator tests, by name
           (timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rccl_$TAG -o rccl -- python -m pytest $R/tests/test_gpu_shard.py -m gpu -q -p no:cacheprovider -k "rccl_one_rank" 2>&1 | tail -5) > $O/rccl_$TAG.log 2>&1; cd $R
           find $O/rccl_$TAG -name "*kernel_stats.csv" -exec cp {} $O/rccl_kernel_stats_$TAG.csv \; ; cat $O/rccl_$TAG.log; cut -c1-160 $O/rccl_kernel_stats_$TAG.csv | head -20; rm -rf $O/rccl_$TAG;;
+    dbg2) (timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --debug-single-device --steps 1 --warmup 0 --no-cpu-baseline --no-profile-pass 2>&1 | grep -v "amdgpu.ids\|Tiled VAE\|Sampling" | tail -12) > $O/bench_n2_single_device_$TAG.log 2>&1; cut -c1-1800 $O/bench_n2_single_device_$TAG.log;;
+    dbg8) (MDTILE_TILE_BATCH=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 8 --debug-single-device --steps 1 --warmup 0 --no-cpu-baseline --no-profile-pass 2>&1 | grep -v "amdgpu.ids\|Tiled VAE\|Sampling" | tail -12) > $O/bench_n8_single_device_$TAG.log 2>&1; cut -c1-1800 $O/bench_n8_single_device_$TAG.log;;
     attn) (timeout 300 python probes/attn_probe.py 30000 77284 2>&1 | grep -v amdgpu.ids) > $O/attn_probe_$TAG.log 2>&1; cat $O/attn_probe_$TAG.log;;
     conv) (timeout 300 python probes/conv_probe.py 2>&1 | grep -v amdgpu.ids) > $O/conv_probe_$TAG.log 2>&1; cat $O/conv_probe_$TAG.log;;
     blend) (timeout 300 python probes/blend_ab.py 2>&1 | grep -v amdgpu.ids) > $O/blend_ab_$TAG.log 2>&1; cat $O/blend_ab_$TAG.log;;
