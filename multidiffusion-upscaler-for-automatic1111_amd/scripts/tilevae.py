@@ -276,6 +276,18 @@ class VAEHook:
                 st.x = self.engine.tanh(st.x)
             st.pc += 1
 
+    def _tile_batch_that_fits(self, N: int, tile_hw: Tuple[int, int], dev) -> int:
+        """Tiles of one shape per sweep (TILE_BATCH at most): what 60 % of the free device memory holds.  Peak of one tile: about five
+        live tensors (residual, fp32 activation, two record images, conv output) of 4 B x 128 channels at the widest level -- 8x the
+        latent tile for the decoder, the image tile itself for the encoder."""
+        if TILE_BATCH <= 1 or torch.device(dev).type != "cuda":
+            return max(1, TILE_BATCH)
+        h, w = tile_hw
+        px = h * w * (64 if self.is_decoder else 1)
+        per_tile = 5 * 4 * 128 * px * N
+        free, _total = torch.cuda.mem_get_info(dev)
+        return max(1, min(TILE_BATCH, int(0.6 * free // max(per_tile, 1))))
+
     # ---- fast mode, every norm frozen: record-image hand-over between the 3x3 convs ----------------------------------
     @staticmethod
     def _takes_rec(step: Step) -> bool:
@@ -448,11 +460,18 @@ class VAEHook:
                 L["flags"].append(torch.isnan(x).all())
                 E.crop_store(x, in_bboxes[i], out_bboxes[i], L["result"], self.is_decoder)
                 L["mine"].append(i)
-        if state.interrupted or per[0]["result"] is None:
+        if all(L["result"] is None for L in per):
+            # interrupted before any tile finished: as the single-device path (and upstream, :644-650)
+            if not self.is_decoder:
+                raise RuntimeError("[Tiled VAE]: interrupted before any encoder tile finished")
             from modules.sd_vae_approx import cheap_approximation
             return torch.cat([torch.nn.functional.interpolate(cheap_approximation(x).unsqueeze(0), scale_factor=8, mode="nearest-exact")
                               for x in z], dim=0).to(devs[0], dtype=dtype)
-        out = per[0]["result"]
+        if per[0]["result"] is None:      # the first device finished nothing (interrupt): it still hosts the assembled canvas
+            with torch.cuda.device(devs[0]):
+                ref_res = next(L["result"] for L in per if L["result"] is not None)
+                per[0]["result"] = torch.zeros(ref_res.shape, device=devs[0], dtype=torch.float32)
+        out = per[0]["result"]             # interrupted runs return the finished tiles, like upstream
         bad = False
         for k, L in enumerate(per):
             torch.cuda.current_stream(devs[k]).synchronize()
@@ -533,24 +552,44 @@ class VAEHook:
                 groups: Dict[Tuple[int, int], List[int]] = {}
                 for i in mine:
                     groups.setdefault(tuple(tiles[i].x.shape[2:]), []).append(i)
+
+                def run_chunk(chunk):
+                    T = len(chunk)
+                    xb = tiles[chunk[0]].x if T == 1 else torch.cat([tiles[i].x for i in chunk], dim=0)
+                    fz = frozen if T == 1 else [(v.repeat(T), m.repeat(T)) for v, m in frozen]
+                    cf = coefs if T == 1 else [c.repeat(T, 1, 1) for c in coefs]
+                    if T > 1:
+                        for i in chunk:
+                            tiles[i].x = None          # the stacked copy is the live one
+                    yb = self._run_tile_rec(steps, xb, fz, cf, norm_ord)
+                    for t, i in enumerate(chunk):
+                        tiles[i].x = yb[t * N:(t + 1) * N]
+                        finish(i)
+
                 for shape_key in sorted(groups, key=lambda kk: -len(groups[kk])):
                     ids = groups[shape_key]
-                    for c0 in range(0, len(ids), TILE_BATCH):
+                    # upstream sizes the TILE so that ONE tile's activations fit the card (:79-99); stacking is only taken when the
+                    # stacked sweep fits what is free right now, and a sweep that still runs out of memory is repeated tile by tile
+                    tb = self._tile_batch_that_fits(N, shape_key, dev)
+                    c0 = 0
+                    while c0 < len(ids):
                         if state.interrupted:
                             interrupted = True
                             break
-                        chunk = ids[c0:c0 + TILE_BATCH]
-                        T = len(chunk)
-                        xb = tiles[chunk[0]].x if T == 1 else torch.cat([tiles[i].x for i in chunk], dim=0)
-                        fz = frozen if T == 1 else [(v.repeat(T), m.repeat(T)) for v, m in frozen]
-                        cf = coefs if T == 1 else [c.repeat(T, 1, 1) for c in coefs]
-                        for i in chunk:
-                            tiles[i].x = None
-                        yb = self._run_tile_rec(steps, xb, fz, cf, norm_ord)
-                        for t, i in enumerate(chunk):
-                            tiles[i].x = yb[t * N:(t + 1) * N]
-                            finish(i)
-                        del xb, yb
+                        chunk = ids[c0:c0 + tb]
+                        try:
+                            run_chunk(chunk)
+                        except torch.cuda.OutOfMemoryError:
+                            if len(chunk) == 1:
+                                raise
+                            print(f"[Tiled VAE]: {len(chunk)} stacked tiles do not fit in VRAM, continuing one tile per sweep")
+                            torch.cuda.empty_cache()
+                            for i in chunk:                # their inputs were folded into the stacked copy: cut them out of z again
+                                b = in_bboxes[i]
+                                tiles[i].x = E.gather_rect(z, b[0], b[2], b[1] - b[0], b[3] - b[2])
+                            tb = 1
+                            continue
+                        c0 += len(chunk)
                     if interrupted:
                         break
                 mine = []        # all done (or interrupted)
