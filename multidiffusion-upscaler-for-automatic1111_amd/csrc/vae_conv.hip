@@ -230,6 +230,8 @@ bool conv_bf16x3_eligible(int cout, int cin, int ksize);
 size_t conv_bf16x3_packed_floats(int cout, int cin);
 int conv_bf16x3_pack(const float* d_w_oihw, void* d_out, int cout, int cin, hipStream_t s);
 bool conv_bf16x3_gn_supported(int cout, int cin, int ksize, int up);
+int conv_bf16x3_down2_launch(const float* d_x, const void* d_w_rec, const float* d_bias, float* d_y, int B, int cin, int cout, int Hin, int Win,
+                             hipStream_t s);
 int conv_bf16x3_launch(const float* d_x, const void* d_w_rec, const float* d_bias, const float* d_res, float* d_y, int B, int cin,
                        int cout, int H, int W, int up, const float* d_coef, hipStream_t s);
 bool conv_rec_narrow_eligible(int cout, int cin, int ksize);
@@ -369,14 +371,16 @@ extern "C" int mdtile_conv2d_rec(const void* d_x_rec, const float* d_w_packed, c
 }
 
 // ldm Downsample: y = conv3x3_stride2(pad(x, right 1, bottom 1)); output (Hin - 2) / 2 + 1 rows (likewise columns).
-// Weights: the fp32 image of mdtile_conv_pack(ksize 3).  Exact-fp32 MFMA kernel (the three downsample convs are ~4 % of the
-// encoder's conv work).
+// Weights: the image of mdtile_conv_pack(ksize 3).  Split-bf16 stride-2 kernel where the 3x3 family is eligible (round 3: the exact
+// kernel made the three downsample convs 9 % of an 8K encode); exact-fp32 MFMA kernel otherwise / under MDTILE_PRECISION_F32.
 extern "C" int mdtile_conv2d_down2(const float* d_x, const float* d_w_packed, const float* d_bias, float* d_y, int B, int cin, int cout,
                                    int Hin, int Win, mdtile_stream_t stream) {
     MDT_CHECK_ARG(d_x && d_w_packed && d_y, "mdtile_conv2d_down2: null argument");
     MDT_CHECK_ARG(B > 0 && B <= 65535 && cin > 0 && cout > 0 && Hin >= 2 && Win >= 2, "mdtile_conv2d_down2: bad shape B=%d cin=%d cout=%d Hin=%d Win=%d",
                   B, cin, cout, Hin, Win);
     MDT_CHECK_ARG((size_t)Hin * Win < (1u << 31), "mdtile_conv2d_down2: input plane of 2^31 or more pixels");
+    if (!conv_strict_f32() && conv_bf16x3_eligible(cout, cin, 3))      // split-bf16 stride-2 kernel (vae_conv_bf16x3.hip, S = 2)
+        return conv_bf16x3_down2_launch(d_x, d_w_packed + f32_packed_floats(cout, cin, 3), d_bias, d_y, B, cin, cout, Hin, Win, as_stream(stream));
     ConvParams P;
     P.x = d_x; P.w = d_w_packed; P.bias = d_bias; P.res = nullptr; P.y = d_y;
     P.B = B; P.Cin = cin; P.Cout = cout; P.CoutP = round_up(cout, 32);

@@ -12,6 +12,12 @@
 //     weight LDS image  [hl][ks 2][mtile][lane 64] x 16 B  (exactly the pre-packed global order: straight copy)
 //   every fragment read is a conflict-free ds_read_b128 of 32 consecutive records per half-wave.
 // Block = 512 threads = 8 waves; wave = 64 couts x NCOL column tiles.
+// These convs are HBM-bound on the wide images (nin_shortcut 256 -> 128 at 2224^2: 7.6 GB against 0.32 TFLOP), so (round 3)
+//   * the operands of phase ph + 2 are requested while phase ph computes (two register sets): two phases = 64 KB of input per CU
+//     in flight instead of one (measured before: 3.4 TB/s of traffic at one phase in flight, ~6 B/clk/CU);
+//   * BM goes up to 256 couts (MT = 8: eight accumulator tiles per wave): 512 -> 256 reads its input once instead of twice.
+#include <type_traits>
+
 #include "common.h"
 
 using namespace mdt;
@@ -52,7 +58,7 @@ __global__ __launch_bounds__(512) void k_conv1x1_bf16x3(const Conv1Params P) {
     constexpr int BM = MT * 32;
     constexpr int WAVES_M = MT / 2, WAVES_C = 8 / WAVES_M, NCOL = 8 / WAVES_C;   // column tiles (32 px) per wave
     constexpr int W_REC = 2 * 2 * MT * 64;           // [hl][ks][mt][lane]
-    constexpr int NWREG = W_REC / 512;               // 2 (MT = 4) or 1 (MT = 2)
+    constexpr int NWREG = W_REC / 512;               // 4 (MT = 8), 2 (MT = 4) or 1 (MT = 2)
     constexpr int IN_STAGE = 2 * IN_REC1;
     __shared__ u32x4 smem[2 * IN_STAGE + 2 * W_REC];
     u32x4* const in_l = smem;
@@ -72,24 +78,24 @@ __global__ __launch_bounds__(512) void k_conv1x1_bf16x3(const Conv1Params P) {
     const int spx = tid & (PXT - 1), sks = tid >> 8;
     const bool pin = p0 + spx < P.HW;
     const size_t soff = pin ? p0 + spx : 0;
-    float rin[2][8];
-    u32x4 rwt[NWREG];
+    float rin[2][2][8];          // [register set][8-channel group][channel]
+    u32x4 rwt[2][NWREG];
 
-    auto load_input = [&](int ph) {       // phase ph: channels 32 ph .. 32 ph + 31
+    auto load_input = [&](int set, int ph) {       // phase ph: channels 32 ph .. 32 ph + 31
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             const float* src = xb + (size_t)(ph * 32 + sks * 16 + g * 8) * P.HW + soff;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) rin[g][j] = src[(size_t)j * P.HW];
+            for (int j = 0; j < 8; ++j) rin[set][g][j] = src[(size_t)j * P.HW];
         }
     };
-    auto store_input = [&](int stage) {
+    auto store_input = [&](int set, int stage) {
         u32x4* dst = in_l + stage * IN_STAGE;
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = pin ? rin[g][j] : 0.0f;
+            for (int j = 0; j < 8; ++j) v[j] = pin ? rin[set][g][j] : 0.0f;
             u32x4 hi, lo;
             split8c(v, hi, lo);
             const int rec = (sks * 2 + g) * PXT + spx;
@@ -98,15 +104,15 @@ __global__ __launch_bounds__(512) void k_conv1x1_bf16x3(const Conv1Params P) {
         }
     };
     const u32x4* wsrc = P.w + (size_t)cb * P.NP * W_REC;
-    auto load_weights = [&](int ph) {
+    auto load_weights = [&](int set, int ph) {
         const u32x4* src = wsrc + (size_t)ph * W_REC;
 #pragma unroll
-        for (int i = 0; i < NWREG; ++i) rwt[i] = src[tid + 512 * i];
+        for (int i = 0; i < NWREG; ++i) rwt[set][i] = src[tid + 512 * i];
     };
-    auto store_weights = [&](int stage) {
+    auto store_weights = [&](int set, int stage) {
         u32x4* dst = w_l + stage * W_REC;
 #pragma unroll
-        for (int i = 0; i < NWREG; ++i) dst[tid + 512 * i] = rwt[i];
+        for (int i = 0; i < NWREG; ++i) dst[tid + 512 * i] = rwt[set][i];
     };
 
     f32x16 acc[2][NCOL];
@@ -117,19 +123,27 @@ __global__ __launch_bounds__(512) void k_conv1x1_bf16x3(const Conv1Params P) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[m][n][q] = 0.0f;
 
-    load_input(0);
-    load_weights(0);
-    store_input(0);
-    store_weights(0);
+    load_input(0, 0);
+    load_weights(0, 0);
+    if (P.NP > 1) {
+        load_input(1, 1);
+        load_weights(1, 1);
+    }
+    store_input(0, 0);
+    store_weights(0, 0);
     __syncthreads();
 
-    for (int ph = 0; ph < P.NP; ++ph) {
-        if (ph + 1 < P.NP) {
-            load_input(ph + 1);
-            load_weights(ph + 1);
+    // phase ph sits in LDS stage ph & 1 and came through register set ph & 1; while it computes, phase ph + 2 is requested into the
+    // same register set (free since its contents went to LDS) and phase ph + 1 -- requested a whole phase ago -- is written to LDS
+    // behind the MFMAs.  Two phases per trip keep the register-set index a compile-time constant.
+    auto phase = [&](int ph, auto set_tag) {
+        constexpr int set = decltype(set_tag)::value;
+        if (ph + 2 < P.NP) {
+            load_input(set, ph + 2);
+            load_weights(set, ph + 2);
         }
-        const u32x4* wst = w_l + (ph & 1) * W_REC;
-        const u32x4* ist = in_l + (ph & 1) * IN_STAGE;
+        const u32x4* wst = w_l + set * W_REC;
+        const u32x4* ist = in_l + set * IN_STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 a[2][2];   // [m][hl]
@@ -151,10 +165,14 @@ __global__ __launch_bounds__(512) void k_conv1x1_bf16x3(const Conv1Params P) {
             }
         }
         if (ph + 1 < P.NP) {
-            store_weights((ph + 1) & 1);
-            store_input((ph + 1) & 1);
+            store_weights(set ^ 1, set ^ 1);
+            store_input(set ^ 1, set ^ 1);
         }
         __syncthreads();
+    };
+    for (int ph = 0; ph < P.NP; ph += 2) {
+        phase(ph, std::integral_constant<int, 0>{});
+        if (ph + 1 < P.NP) phase(ph + 1, std::integral_constant<int, 1>{});
     }
 
     // epilogue: + bias (+ residual).  C/D layout of a 32x32 MFMA: col = lane & 31, row = (q&3) + 8*(q>>2) + 4*(lane>>5)
@@ -220,7 +238,7 @@ inline int round_up1(int v, int m) { return (v + m - 1) / m * m; }
 namespace mdt {
 
 bool conv1x1_bf16x3_eligible(int cout, int cin) { return cin % 32 == 0 && cout >= 32; }
-static int conv1x1_mt(int cout) { return cout > 64 ? 4 : 2; }
+static int conv1x1_mt(int cout) { return cout > 128 ? 8 : (cout > 64 ? 4 : 2); }
 
 size_t conv1x1_bf16x3_packed_floats(int cout, int cin) {
     const int MT = conv1x1_mt(cout), NCB = round_up1(cout, MT * 32) / (MT * 32), NP = cin / 32;
@@ -245,7 +263,8 @@ int conv1x1_bf16x3_launch(const float* d_x, const void* d_w_rec, const float* d_
     P.NCB = round_up1(cout, MT * 32) / (MT * 32);
     P.NP = cin / 32;
     dim3 grid(((P.ptiles + 7) / 8) * 8 * P.NCB, B), block(512);
-    if (MT == 4) hipLaunchKernelGGL(k_conv1x1_bf16x3<4>, grid, block, 0, s, P);
+    if (MT == 8) hipLaunchKernelGGL(k_conv1x1_bf16x3<8>, grid, block, 0, s, P);
+    else if (MT == 4) hipLaunchKernelGGL(k_conv1x1_bf16x3<4>, grid, block, 0, s, P);
     else hipLaunchKernelGGL(k_conv1x1_bf16x3<2>, grid, block, 0, s, P);
     MDT_LAUNCH_CHECK();
     return MDTILE_OK;

@@ -76,13 +76,19 @@ __device__ __host__ __forceinline__ int kstep_cj(int j, int perm) { return perm 
 //           overwritten, once per K-step), 124 VGPR + 71 KB LDS -> TWO blocks per CU (4 waves per SIMD); MFMAs issued
 //           term-major across the accumulators of a tap column (a dependent MFMA is >= 4 MFMAs away)
 //   MT = 2 (64 couts, small decoders): weights through VGPRs, two input stages
-template <int MT, bool GNS>
-__global__ __launch_bounds__(512, MT == 4 ? 4 : 2) void k_conv3x3_bf16x3(const ConvBParams P) {
+// S = 2 (round 3): ldm's Downsample of the ENCODER (scripts/tilevae.py:155-171: conv 3x3, stride 2, over pad(x, right 1, bottom 1)) on
+// the same split-bf16 arithmetic.  Output tile 8 x 32 px, input halo tile 17 x 65; the LDS image keeps the two COLUMN PARITIES of a
+// row apart ([cg][row 17][parity 2][33]) so that the fragment of tap dx -- input columns 2 x + dx of 32 consecutive output px -- is
+// again 32 consecutive records (a stride-2 ds_read_b128 would be a 2-way bank conflict).  Zero padding only right / bottom.
+template <int MT, bool GNS, int S = 1>
+__global__ __launch_bounds__(512, (MT == 4 && S == 1) ? 4 : 2) void k_conv3x3_bf16x3(const ConvBParams P) {
     constexpr int TH_ = 8;
-    constexpr bool WDMA = MT == 4, IB1 = MT == 4, TERM_MAJOR = MT == 4;
+    constexpr bool WDMA = MT == 4, IB1 = MT == 4 || S == 2, TERM_MAJOR = MT == 4;   // (S = 2: the 72 KB halo tile exists once)
     constexpr int BM = MT * 32;
     constexpr int WAVES_M = MT / 2, WAVES_R = 8 / WAVES_M, NROW = TH_ / WAVES_R;
-    constexpr int ROWS_ = TH_ + 2, IN_REC_ = 2 * ROWS_ * COLS;   // halo tile records per hl per stage
+    constexpr int HCOL = TW + 1;                                   // S = 2: records per column parity of a row
+    constexpr int COLSL = S == 1 ? COLS : 2 * HCOL;                // records per LDS row
+    constexpr int ROWS_ = S == 1 ? TH_ + 2 : 2 * TH_ + 1, IN_REC_ = 2 * ROWS_ * COLSL;   // halo tile records per hl per stage
     constexpr int NPASS = (IN_REC_ + 511) / 512;                  // staging passes of the 512 threads
     constexpr int W_REC = 2 * 3 * MT * 64;              // records per weight chunk (hi block then lo block)
     constexpr int NWREG = (W_REC + 511) / 512;          // 3 (MT = 4) or 2 (MT = 2, half of the threads on the 2nd)
@@ -124,10 +130,18 @@ __global__ __launch_bounds__(512, MT == 4 ? 4 : 2) void k_conv3x3_bf16x3(const C
     for (int i = 0; i < NPASS; ++i) {
         int s = tid + 512 * i;
         if (s >= IN_REC_) s = IN_REC_ - 1;                      // lanes past the end shadow the last record (never stored)
-        const int cg = s / (ROWS_ * COLS), p = s - cg * (ROWS_ * COLS);
-        const int r = p / COLS, c = p - r * COLS;
-        const int gy = y0 + r - 1, gx = x0 + c - 1;
-        const bool inside = gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
+        const int cg = s / (ROWS_ * COLSL), p = s - cg * (ROWS_ * COLSL);
+        const int r = p / COLSL, c = p - r * COLSL;
+        int gy, gx;
+        bool inside;
+        if (S == 1) {
+            gy = y0 + r - 1; gx = x0 + c - 1;
+            inside = gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
+        } else {           // LDS column c = parity * HCOL + i  <->  input column 2 i + parity of the halo tile (65 of the 66 slots are used)
+            const int par = c / HCOL, ci = c - par * HCOL, col = 2 * ci + par;
+            gy = 2 * y0 + r; gx = 2 * x0 + col;
+            inside = col <= 2 * TW && gy < P.Hin && gx < P.Win;
+        }
         scg[i] = cg;
         soff[i] = inside ? gy * P.Win + gx : 0;
         smask[i] = inside ? 1.0f : 0.0f;
@@ -234,7 +248,8 @@ __global__ __launch_bounds__(512, MT == 4 ? 4 : 2) void k_conv3x3_bf16x3(const C
                 bf16x8 bh[NROW], bl[NROW];
 #pragma unroll
                 for (int n = 0; n < NROW; ++n) {
-                    const int rec = (kg * ROWS_ + wr * NROW + n + dy) * COLS + l31 + dx;
+                    const int rec = S == 1 ? (kg * ROWS_ + wr * NROW + n + dy) * COLS + l31 + dx
+                                           : (kg * ROWS_ + 2 * (wr * NROW + n) + dy) * COLSL + (dx & 1) * HCOL + l31 + (dx >> 1);
                     bh[n] = __builtin_bit_cast(bf16x8, ist[rec]);
                     bl[n] = __builtin_bit_cast(bf16x8, ist[IN_REC_ + rec]);
                 }
@@ -250,7 +265,8 @@ __global__ __launch_bounds__(512, MT == 4 ? 4 : 2) void k_conv3x3_bf16x3(const C
             } else {
 #pragma unroll
                 for (int n = 0; n < NROW; ++n) {
-                    const int rec = (kg * ROWS_ + wr * NROW + n + dy) * COLS + l31 + dx;
+                    const int rec = S == 1 ? (kg * ROWS_ + wr * NROW + n + dy) * COLS + l31 + dx
+                                           : (kg * ROWS_ + 2 * (wr * NROW + n) + dy) * COLSL + (dx & 1) * HCOL + l31 + (dx >> 1);
                     const bf16x8 bh = __builtin_bit_cast(bf16x8, ist[rec]), bl = __builtin_bit_cast(bf16x8, ist[IN_REC_ + rec]);
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
@@ -651,6 +667,27 @@ int conv_bf16x3_launch(const float* d_x, const void* d_w_rec, const float* d_bia
         if (d_coef) hipLaunchKernelGGL((k_conv3x3_bf16x3<2, true>), grid, block, 0, s, P);
         else hipLaunchKernelGGL((k_conv3x3_bf16x3<2, false>), grid, block, 0, s, P);
     }
+    MDT_LAUNCH_CHECK();
+    return MDTILE_OK;
+}
+
+// ldm Downsample (encoder): conv3x3 stride 2 over pad(x, right 1, bottom 1); output (Hin - 2) / 2 + 1 rows / columns
+int conv_bf16x3_down2_launch(const float* d_x, const void* d_w_rec, const float* d_bias, float* d_y, int B, int cin, int cout, int Hin, int Win,
+                             hipStream_t s) {
+    ConvBParams P;
+    P.perm = conv_bf16x3_perm(cin);
+    P.coef = nullptr;
+    P.x = d_x; P.w = (const u32x4*)d_w_rec; P.bias = d_bias; P.res = nullptr; P.y = d_y;
+    P.B = B; P.Cin = cin; P.Cout = cout; P.H = (Hin - 2) / 2 + 1; P.W = (Win - 2) / 2 + 1;
+    P.Hin = Hin; P.Win = Win; P.up = 0;
+    const int MT = conv_bf16x3_mt(cout);
+    P.NCB = round_up_i(cout, MT * 32) / (MT * 32);
+    P.NK = cin / 16;
+    P.PX = (P.W + TW - 1) / TW;
+    P.ptiles = P.PX * ((P.H + TH - 1) / TH);
+    dim3 grid(((P.ptiles + 7) / 8) * 8 * P.NCB, B), block(512);
+    if (MT == 4) hipLaunchKernelGGL((k_conv3x3_bf16x3<4, false, 2>), grid, block, 0, s, P);
+    else hipLaunchKernelGGL((k_conv3x3_bf16x3<2, false, 2>), grid, block, 0, s, P);
     MDT_LAUNCH_CHECK();
     return MDTILE_OK;
 }

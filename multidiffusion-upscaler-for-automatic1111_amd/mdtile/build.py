@@ -74,6 +74,15 @@ def build(force: bool = False, verbose: bool = True) -> str:
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
+    # build-time guard of the hand-counted LDS-DMA protocol (M0 save / set / restore around every global_load_lds, the counted vmcnt
+    # waits in front of the barriers): checked on the emitted device assembly, so a compiler upgrade cannot break it silently
+    guard = os.path.join(os.path.dirname(EXT_ROOT), "tools", "asm_guard.py")
+    if os.path.exists(guard) and os.environ.get("MDTILE_SKIP_ASM_GUARD", "") != "1":
+        g = subprocess.run([sys.executable, guard], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if g.returncode != 0:
+            raise RuntimeError(f"tools/asm_guard.py rejected the device code of the record conv / attention kernels:\n{g.stdout}")
+        if verbose:
+            print(g.stdout.rstrip())
     with open(STAMP, "w") as f:
         f.write(digest)
     if verbose:

@@ -83,6 +83,8 @@ CONV_CASES = [  # B, cin, cout, k, H, W, upsample, residual, token_major
     (1, 256, 128, 1, 40, 50, False, False, False),   # split-bf16 1x1, one cout block
     (1, 96, 64, 1, 17, 19, False, True, False),      # split-bf16 1x1, 64-cout block variant, 3 phases, ragged last pixel tile
     (1, 512, 512, 1, 31, 33, False, True, False),    # proj_out shape (+ the queue's residual add)
+    (1, 32, 160, 1, 23, 29, False, True, False),     # split-bf16 1x1, ONE phase (no prefetch), 256-cout block variant with 160 real couts
+    (1, 160, 320, 1, 10, 50, False, False, False),   # split-bf16 1x1, 5 phases (odd: the two-phase trip ends half way), 2 cout blocks of 256
 ]
 
 
@@ -397,3 +399,27 @@ def test_stacked_sweep_falls_back_to_single_tiles_on_oom(plugin, cuda, monkeypat
     assert torch.equal(out, ref)
     # the batch is also bounded by what is free: a tile that "needs" more than the card has gets batch 1
     assert hook._tile_batch_that_fits(1, (10 ** 5, 10 ** 5), cuda) == 1 and hook._tile_batch_that_fits(1, (16, 16), cuda) == 3
+
+
+@pytest.mark.parametrize("B,cin,cout,H,W", [(1, 128, 128, 67, 130), (2, 64, 64, 40, 37), (1, 32, 48, 16, 66), (1, 256, 256, 90, 64), (1, 128, 128, 2, 2),
+                                            (1, 48, 160, 33, 35)])
+@pytest.mark.parametrize("exact", [False, True], ids=["bf16x3", "f32"])
+def test_downsample_conv_vs_torch(plugin, cuda, B, cin, cout, H, W, exact):
+    """ldm Downsample (encoder task, upstream scripts/tilevae.py:155-171): conv3x3 stride 2 over pad(x, right 1, bottom 1) -- the
+    split-bf16 stride-2 kernel (default) and the exact-fp32 MFMA kernel (MDTILE_PRECISION_F32) against torch fp32."""
+    E = plugin.engine
+    torch.manual_seed(cin + cout + H)
+    conv = torch.nn.Conv2d(cin, cout, 3, 2, 0)
+    x = torch.randn(B, cin, H, W)
+    with torch.no_grad():
+        ref = conv(F.pad(x, (0, 1, 0, 1)))
+    pc = E.PackedConv(conv.weight.detach().to(cuda), conv.bias.detach().to(cuda))
+    try:
+        if exact:
+            E.set_precision(E.PRECISION_F32)
+        out = pc.down2(x.to(cuda)).cpu()
+    finally:
+        E.set_precision(E.PRECISION_BF16X3)
+    assert out.shape == ref.shape
+    err = _rel(out, ref)
+    assert err < (2e-5 if exact else 5e-5), f"downsample conv rel err {err}"

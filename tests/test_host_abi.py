@@ -83,6 +83,16 @@ def test_best_tile_size_matches_upstream(built_lib):
                 assert got == ref_hook.get_best_tile_size(lower, upper), (lower, upper)
 
 
+def test_dma_protocol_in_the_device_assembly():
+    """tools/asm_guard.py: the M0 save / set / s_nop / global_load_lds / restore quintuples and the vmcnt values counted in front of the
+    barriers of the record conv and attention kernels, checked on hipcc's device assembly (also run by mdtile.build after a rebuild)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asm_guard.py")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    assert r.stdout.count(" ok") == 6, r.stdout
+
+
 def test_no_cpu_fallback(built_lib):
     x = torch.zeros(1, 4, 16, 16)
     with pytest.raises(built_lib.MdtileError, match="no CPU fallback"):

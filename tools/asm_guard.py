@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""Build-time guard for the hand-counted LDS-DMA protocol of the record conv / attention kernels (csrc/vae_conv_rec.hip: dma16,
+csrc/vae_attn_bf16x3.hip: dma16a).  The kernels issue `global_load_lds_dwordx4` from inline asm (hipcc would book the builtin as a
+FLAT access and degrade every later lgkmcnt wait) and count its completion by hand: M0 is saved, loaded with the LDS destination,
+`s_nop 2`, the DMA, M0 restored; every consumer sits behind `s_waitcnt vmcnt(0)` (or the one counted `vmcnt(5)`) + `s_barrier`.
+A compiler upgrade that re-orders or drops any of that would only show up as wrong pixels; this script compiles the two files to
+device assembly and checks the emitted instruction stream instead:
+    * every global_load_lds_dwordx4 is the 4th instruction of   s_mov_b32 sK, m0 / s_mov_b32 m0, sL / s_nop 2 / DMA / s_mov_b32 m0, sK
+    * no `s_waitcnt` with a vmcnt between a DMA and its M0 restore, no other M0 writer inside the quintuple
+    * every s_barrier is directly preceded (ignoring scalar ALU) by an s_waitcnt, and the vmcnt values those waits count are exactly
+      the ones the source asks for: {0, 5} in k_conv3x3_rec (the 5 input pieces of the next K-step may stay in flight at dy = 1),
+      {0} in k_upconv_rec and k_attn_bf16x3 (lgkmcnt-only waits -- LDS hand-overs that consume no DMA -- are reported separately)
+    * MFMA counts per unrolled trip match the source (conv: 36 half-steps x 12; upconv: 24 combo-steps x 12; attention: 24 / slab)
+usage: python tools/asm_guard.py   (exit code 0 = ok; prints one line per kernel)      -- also run by tests/test_host_abi.py
+"""
+from __future__ import annotations
+
+import collections
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "multidiffusion-upscaler-for-automatic1111_amd", "csrc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-pragma-unroll-threshold=262144", "-S", "--cuda-device-only"]
+
+
+def device_asm(src: str) -> list:
+    hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "k.s")
+        r = subprocess.run([hipcc] + FLAGS + [src, "-o", out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc -S failed on {src}:\n{r.stdout}")
+        return open(out).read().splitlines()
+
+
+def kernels(lines: list) -> dict:
+    """mangled name -> list of instructions (labels, directives and comments stripped)"""
+    out, cur = {}, None
+    for l in lines:
+        m = re.match(r"^(_Z[A-Za-z0-9_]+):", l)
+        if m:
+            cur = m.group(1)
+            out[cur] = []
+            continue
+        if cur is None:
+            continue
+        t = l.split(";")[0].strip()
+        if not t or t.startswith(".") or t.endswith(":"):
+            continue
+        out[cur].append(t)
+        if t == "s_endpgm":
+            cur = None
+    return out
+
+
+SREG = r"(?:s\d+|vcc_lo|vcc_hi|ttmp\d+)"
+
+
+def check_kernel(name: str, ins: list, expect: dict) -> list:
+    errs = []
+    dma = [k for k, l in enumerate(ins) if l.startswith("global_load_lds_dwordx4")]
+    for k in dma:
+        if k < 3 or k + 1 >= len(ins):
+            errs.append(f"DMA at {k}: no room for the M0 protocol")
+            continue
+        a, b, c, e = ins[k - 3], ins[k - 2], ins[k - 1], ins[k + 1]
+        ma = re.match(r"s_mov_b32 (" + SREG + r"), m0$", a)
+        ok = bool(ma) and re.match(r"s_mov_b32 m0, " + SREG + r"$", b) and c.startswith("s_nop") and ma and e == f"s_mov_b32 m0, {ma.group(1)}"
+        if not ok:
+            errs.append(f"DMA at {k}: expected save-M0 / set-M0 / s_nop / DMA / restore-M0, got {ins[k - 3:k + 2]}")
+    bars = [k for k, l in enumerate(ins) if l.startswith("s_barrier")]
+    bar_waits = []
+    for k in bars:
+        j = k - 1
+        while j >= 0 and re.match(r"s_(mov|add|and|or|lshl|lshr|mul|cmp|cselect|sub|ashr|bfe|nop|xor|not|max|min|addc|bitcmp)", ins[j]):
+            j -= 1
+        if not (j >= 0 and ins[j].startswith("s_waitcnt")):
+            errs.append(f"s_barrier at {k} is not preceded by an s_waitcnt (found {ins[max(0, j)]})")
+            continue
+        m = re.search(r"vmcnt\((\d+)\)", ins[j])
+        bar_waits.append(int(m.group(1)) if m else None)      # None: an lgkmcnt-only wait (LDS hand-over, no DMA consumed behind it)
+    counted = {w for w in bar_waits if w is not None}
+    n_mfma = sum(1 for l in ins if l.startswith("v_mfma_f32_32x32x16_bf16"))
+    for key, val in expect.items():
+        if key == "dma_min" and len(dma) < val:
+            errs.append(f"{len(dma)} DMA instructions < {val}")
+        if key == "barrier_vmcnt" and counted != set(val):
+            errs.append(f"the waits in front of the barriers count vmcnt {sorted(counted)}, the DMA protocol expects exactly {sorted(val)}")
+        if key == "mfma_multiple" and (n_mfma == 0 or n_mfma % val):
+            errs.append(f"{n_mfma} MFMAs is not a multiple of {val}")
+    print(f"{name[:70]:70s} {len(ins):6d} instr  {len(dma):3d} DMA  {len(bars):3d} barriers (vmcnt in front: {sorted(counted)}, lgkm-only: {bar_waits.count(None)})  "
+          f"{n_mfma:4d} MFMA  {'ok' if not errs else 'FAIL'}")
+    return [f"{name}: {e}" for e in errs]
+
+
+def main() -> int:
+    errs = []
+    rec = kernels(device_asm(os.path.join(CSRC, "vae_conv_rec.hip")))
+    att = kernels(device_asm(os.path.join(CSRC, "vae_attn_bf16x3.hip")))
+    plan = [
+        (rec, "k_conv3x3_recILi2ELi2ELi4", dict(dma_min=8, barrier_vmcnt=[0, 5], mfma_multiple=12)),
+        (rec, "k_conv3x3_recILi1ELi1ELi2", dict(dma_min=4, barrier_vmcnt=[0, 5], mfma_multiple=3)),
+        (rec, "k_upconv_rec", dict(dma_min=8, barrier_vmcnt=[0], mfma_multiple=12)),
+        (att, "k_attn_bf16x3ILi512", dict(dma_min=8, barrier_vmcnt=[0], mfma_multiple=6)),
+        (att, "k_attn_bf16x3ILi256", dict(dma_min=8, barrier_vmcnt=[0], mfma_multiple=6)),
+        (att, "k_attn_bf16x3ILi128", dict(dma_min=8, barrier_vmcnt=[0], mfma_multiple=6)),
+    ]
+    for table, sub, expect in plan:
+        hit = [n for n in table if sub in n]
+        if not hit:
+            errs.append(f"kernel {sub} not found in the device assembly")
+            continue
+        errs += check_kernel(hit[0], table[hit[0]], expect)
+    for e in errs:
+        print("ASM GUARD:", e)
+    return 1 if errs else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

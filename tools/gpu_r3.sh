@@ -24,6 +24,9 @@ for w in $WHAT; do
           find $O/rccl_$TAG -name "*kernel_stats.csv" -exec cp {} $O/rccl_kernel_stats_$TAG.csv \; ; cat $O/rccl_$TAG.log; cut -c1-160 $O/rccl_kernel_stats_$TAG.csv | head -20; rm -rf $O/rccl_$TAG;;
     dbg2) (timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --debug-single-device --steps 1 --warmup 0 --no-cpu-baseline --no-profile-pass 2>&1 | grep -v "amdgpu.ids\|Tiled VAE\|Sampling" | tail -12) > $O/bench_n2_single_device_$TAG.log 2>&1; cut -c1-1800 $O/bench_n2_single_device_$TAG.log;;
     dbg8) (MDTILE_TILE_BATCH=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 8 --debug-single-device --steps 1 --warmup 0 --no-cpu-baseline --no-profile-pass 2>&1 | grep -v "amdgpu.ids\|Tiled VAE\|Sampling" | tail -12) > $O/bench_n8_single_device_$TAG.log 2>&1; cut -c1-1800 $O/bench_n8_single_device_$TAG.log;;
+    vae) (timeout 900 python -m pytest tests/test_gpu_vae.py tests/test_gpu_rec.py -m gpu -q --tb=short -p no:cacheprovider 2>&1 | grep -v "Tiled VAE\|amdgpu.ids" | tail -40) > $O/pytest_vae_$TAG.log 2>&1; tail -25 $O/pytest_vae_$TAG.log;;
+    c1x1) (timeout 300 python probes/conv1x1_probe.py 2>&1 | grep -v amdgpu.ids) > $O/conv1x1_probe_$TAG.log 2>&1; cat $O/conv1x1_probe_$TAG.log;;
+    enc) (timeout 600 python probes/encode_probe.py 2>&1 | grep -v amdgpu.ids) > $O/encode_probe_$TAG.log 2>&1; cat $O/encode_probe_$TAG.log;;
     attn) (timeout 300 python probes/attn_probe.py 30000 77284 2>&1 | grep -v amdgpu.ids) > $O/attn_probe_$TAG.log 2>&1; cat $O/attn_probe_$TAG.log;;
     conv) (timeout 300 python probes/conv_probe.py 2>&1 | grep -v amdgpu.ids) > $O/conv_probe_$TAG.log 2>&1; cat $O/conv_probe_$TAG.log;;
     blend) (timeout 300 python probes/blend_ab.py 2>&1 | grep -v amdgpu.ids) > $O/blend_ab_$TAG.log 2>&1; cat $O/blend_ab_$TAG.log;;
