@@ -39,8 +39,6 @@ struct Conv1Params {
     int ptiles, NCB, NP; // 256-pixel tiles, cout blocks, 32-channel phases
 };
 
-constexpr int PXT = 256;                       // pixels per block
-constexpr int IN_REC1 = 2 * 2 * PXT;           // records per hl per stage: [ks][kg][px]
 
 __device__ __forceinline__ void split8c(const float (&v)[8], u32x4& hi, u32x4& lo) {
     bf16x8 h, l;
@@ -53,10 +51,16 @@ __device__ __forceinline__ void split8c(const float (&v)[8], u32x4& hi, u32x4& l
     lo = __builtin_bit_cast(u32x4, l);
 }
 
-template <int MT>
-__global__ __launch_bounds__(512) void k_conv1x1_bf16x3(const Conv1Params P) {
+// PXT = pixels per block.  128-cout blocks take 128 px: 64 KB of LDS and ~100 registers -> TWO blocks per CU, so that the store-bound
+// epilogue of one block (128 couts x 128 px x 4 B through 4-byte-per-lane stores) runs under the K loop of the other; with one
+// resident block per CU the epilogue was fully exposed (256 -> 128 at 2224^2: ~30 us per block of which ~half epilogue).
+template <int MT, int PXT>
+__global__ __launch_bounds__(512, PXT == 128 ? 4 : 2) void k_conv1x1_bf16x3(const Conv1Params P) {
     constexpr int BM = MT * 32;
-    constexpr int WAVES_M = MT / 2, WAVES_C = 8 / WAVES_M, NCOL = 8 / WAVES_C;   // column tiles (32 px) per wave
+    constexpr int IN_REC1 = 2 * 2 * PXT;             // records per hl per stage: [ks][kg][px]
+    constexpr int NG = PXT / 128;                    // 8-channel groups a thread stages per phase (512 threads x NG = 4 groups x PXT px)
+    constexpr int WAVES_M = MT / 2, WAVES_C = 8 / WAVES_M, NCOL = (PXT / 32) / WAVES_C;   // column tiles (32 px) per wave
+    static_assert(NCOL >= 1 && NG >= 1, "block shape");
     constexpr int W_REC = 2 * 2 * MT * 64;           // [hl][ks][mt][lane]
     constexpr int NWREG = W_REC / 512;               // 4 (MT = 8), 2 (MT = 4) or 1 (MT = 2)
     constexpr int IN_STAGE = 2 * IN_REC1;
@@ -74,17 +78,18 @@ __global__ __launch_bounds__(512) void k_conv1x1_bf16x3(const Conv1Params P) {
     const int wm = wave % WAVES_M, wc = wave / WAVES_M;
     const float* xb = P.x + (size_t)b * P.Cin * P.HW;
 
-    // staging map: thread -> pixel (tid & 255), K-step (tid >> 8); it fills both 8-channel groups of that (ks, px)
-    const int spx = tid & (PXT - 1), sks = tid >> 8;
+    // staging map: thread -> pixel (tid % PXT) and NG consecutive 8-channel groups gi = (tid / PXT) * NG + g of the phase's four
+    // (gi = 2 * K-step + kg: channels 32 ph + 8 gi + j, LDS record gi * PXT + px)
+    const int spx = tid & (PXT - 1), sgb = (tid / PXT) * NG;
     const bool pin = p0 + spx < P.HW;
     const size_t soff = pin ? p0 + spx : 0;
-    float rin[2][2][8];          // [register set][8-channel group][channel]
+    float rin[2][NG][8];         // [register set][8-channel group][channel]
     u32x4 rwt[2][NWREG];
 
     auto load_input = [&](int set, int ph) {       // phase ph: channels 32 ph .. 32 ph + 31
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const float* src = xb + (size_t)(ph * 32 + sks * 16 + g * 8) * P.HW + soff;
+        for (int g = 0; g < NG; ++g) {
+            const float* src = xb + (size_t)(ph * 32 + (sgb + g) * 8) * P.HW + soff;
 #pragma unroll
             for (int j = 0; j < 8; ++j) rin[set][g][j] = src[(size_t)j * P.HW];
         }
@@ -92,13 +97,13 @@ __global__ __launch_bounds__(512) void k_conv1x1_bf16x3(const Conv1Params P) {
     auto store_input = [&](int set, int stage) {
         u32x4* dst = in_l + stage * IN_STAGE;
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
+        for (int g = 0; g < NG; ++g) {
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = pin ? rin[set][g][j] : 0.0f;
             u32x4 hi, lo;
             split8c(v, hi, lo);
-            const int rec = (sks * 2 + g) * PXT + spx;
+            const int rec = (sgb + g) * PXT + spx;
             dst[rec] = hi;
             dst[IN_REC1 + rec] = lo;
         }
@@ -238,7 +243,11 @@ inline int round_up1(int v, int m) { return (v + m - 1) / m * m; }
 namespace mdt {
 
 bool conv1x1_bf16x3_eligible(int cout, int cin) { return cin % 32 == 0 && cout >= 32; }
-static int conv1x1_mt(int cout) { return cout > 128 ? 8 : (cout > 64 ? 4 : 2); }
+static int conv1x1_mt(int cout) {
+    // MDTILE_C1X1_MT8=0 (probing, read once: packing and launch must agree): 128-cout blocks also for wider convs
+    static const bool mt8 = [] { const char* e = getenv("MDTILE_C1X1_MT8"); return !(e && e[0] == '0'); }();
+    return cout > 128 && mt8 ? 8 : (cout > 64 ? 4 : 2);
+}
 
 size_t conv1x1_bf16x3_packed_floats(int cout, int cin) {
     const int MT = conv1x1_mt(cout), NCB = round_up1(cout, MT * 32) / (MT * 32), NP = cin / 32;
@@ -259,13 +268,14 @@ int conv1x1_bf16x3_launch(const float* d_x, const void* d_w_rec, const float* d_
     P.x = d_x; P.w = (const u32x4*)d_w_rec; P.bias = d_bias; P.res = d_res; P.y = d_y;
     P.B = B; P.Cin = cin; P.Cout = cout; P.HW = HW;
     const int MT = conv1x1_mt(cout);
+    const int PXT = MT == 4 ? 128 : 256;
     P.ptiles = (int)((HW + PXT - 1) / PXT);
     P.NCB = round_up1(cout, MT * 32) / (MT * 32);
     P.NP = cin / 32;
     dim3 grid(((P.ptiles + 7) / 8) * 8 * P.NCB, B), block(512);
-    if (MT == 8) hipLaunchKernelGGL(k_conv1x1_bf16x3<8>, grid, block, 0, s, P);
-    else if (MT == 4) hipLaunchKernelGGL(k_conv1x1_bf16x3<4>, grid, block, 0, s, P);
-    else hipLaunchKernelGGL(k_conv1x1_bf16x3<2>, grid, block, 0, s, P);
+    if (MT == 8) hipLaunchKernelGGL((k_conv1x1_bf16x3<8, 256>), grid, block, 0, s, P);
+    else if (MT == 4) hipLaunchKernelGGL((k_conv1x1_bf16x3<4, 128>), grid, block, 0, s, P);
+    else hipLaunchKernelGGL((k_conv1x1_bf16x3<2, 256>), grid, block, 0, s, P);
     MDT_LAUNCH_CHECK();
     return MDTILE_OK;
 }
