@@ -146,8 +146,22 @@ def main():
             if os.environ.get("MDTILE_SHARD_TORCH", "") != "1" and sharding.init_process_context_checked(rank, world, local_rank):
                 transport = "rccl (engine communicator, C ABI)"
             else:
-                sharding.set_data_group(dist.new_group(backend="nccl", device_id=dev))
-                transport = "rccl (torch.distributed nccl group)"
+                try:      # the ONE alternative communicator: torch's RCCL backend for the same data-plane calls
+                    grp = dist.new_group(backend="nccl", device_id=dev)
+                    probe = torch.ones(1, device=dev)
+                    dist.all_reduce(probe, group=grp)
+                    torch.cuda.synchronize()
+                    ok = float(probe.item()) == float(world)
+                except Exception as e:      # noqa: BLE001 -- reported in the JSON line; the run continues host-staged over gloo
+                    print(f"[bench] rank {rank}: torch nccl group unavailable ({e!r})", file=sys.stderr)
+                    ok = False
+                flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 1:
+                    sharding.set_data_group(grp)
+                    transport = "rccl (torch.distributed nccl group)"
+                else:
+                    transport = "gloo (host-staged: neither RCCL communicator came up)"
     from oracle import ldm_decoder as ld  # only for the random-weight SD-shaped decoder definition
 
     L, N, C = args.latent, 2, 4
