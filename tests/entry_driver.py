@@ -146,6 +146,16 @@ def drive(mods, case, device="cpu", build_regions=None):
             out = smp.model_wrap_cfg.inner_model.forward(x, sig, cond=cond)
             outs.append(out)
             x = x - out * 0.25
+        # hires second pass: a latent of another spatial size bypasses the tiling entirely (multidiffusion.py:140-144) -- one model call
+        # with the sampler's own arguments
+        if not case["i2i"] and not case["regions"]:
+            n0 = len(calls)
+            xs = x[:, :, :case["H"] // 2, :case["W"] // 2].contiguous()
+            sig = torch.full((case["N"],), 0.5, device=device)
+            direct = make_model([])(xs, sig, cond=cond)
+            byp = smp.model_wrap_cfg.inner_model.forward(xs, sig, cond=cond)
+            assert len(calls) == n0 + 1 and torch.equal(byp, direct), "size mismatch must fall through to the original forward"
+            del calls[n0:]
         return torch.stack(outs), calls
     finally:
         C.reconstruct_cond, C.reconstruct_uncond = old
