@@ -28,6 +28,8 @@ ENTRY_CASES = [
     dict(name="kdiff_sdxl_i2i", sampler="kdiff", style="sdxl", i2i=True, regions=False, N=2, W=50, H=36, tw=16, th=16, ov=4, bs=4),
     dict(name="kdiff_sd1_i2i_regions", sampler="kdiff", style="sd1", i2i=True, regions=True, N=2, W=56, H=40, tw=24, th=16, ov=8, bs=3),
     dict(name="kdiff_batch1", sampler="kdiff", style="sd1", i2i=True, regions=False, N=1, W=40, H=40, tw=16, th=24, ov=8, bs=2),
+    dict(name="kdiff_batch2_sdxl", sampler="kdiff", style="sdxl", i2i=True, regions=False, N=4, W=48, H=48, tw=24, th=24, ov=12, bs=4),   # batch 2 x (cond, uncond)
+    dict(name="kdiff_single_tile_batches", sampler="kdiff", style="sd1", i2i=True, regions=False, N=2, W=56, H=40, tw=24, th=16, ov=8, bs=1),   # tile batch 1: repeat_tensor's n == 1 path
     dict(name="ddim_dict_i2i", sampler="ddim", style="sd1", i2i=True, regions=False, N=2, W=56, H=40, tw=24, th=16, ov=8, bs=3),
     dict(name="ddim_tensor_cond", sampler="ddim", style="tensor", i2i=False, regions=False, N=2, W=56, H=40, tw=24, th=16, ov=8, bs=3),
     dict(name="ddim_dict_i2i_regions", sampler="ddim", style="sd1", i2i=True, regions=True, N=1, W=56, H=40, tw=24, th=16, ov=8, bs=3),
