@@ -351,7 +351,7 @@ def main():
                 flops = 2.0 * B * H * W * self.cout * cin * self.ksize * self.ksize
                 bf = subpixel and not exact and not token_major and cin % 16 == 0
                 if self.ksize == 1:
-                    tag = "k_conv1x1_bf16x3<*>" if (bf and cin % 32 == 0) else "k_conv<1,*> (exact fp32 MFMA)"
+                    tag = "k_conv1x1_stream<*> / k_conv1x1_bf16x3<*>" if (bf and cin % 32 == 0) else "k_conv<1,*> (exact fp32 MFMA)"
                 elif upsample2x and bf:
                     flops *= 4.0 / 9.0      # sub-pixel form of nearest-2x + 3x3 conv: four 2x2 convs -> 4/9 of the MACs are EXECUTED
                     tag = "k_upconv_bf16x3<*> (fp32 hand-over)"
@@ -373,9 +373,10 @@ def main():
 
             orig_attn = E.vae_attn
 
-            def timed_attn(q, k, v, scale):
+            def timed_attn(q, k, v, scale, exact=False, v_channel_major=False):
                 B, Cc, T = q.shape
-                return prof.wrap("k_attn_bf16x3<512>" if subpixel else "k_attn<*> (exact fp32 MFMA)", 4.0 * B * T * T * Cc, lambda: orig_attn(q, k, v, scale))
+                return prof.wrap("k_attn_bf16x3<512>" if subpixel and not exact else "k_attn<*> (exact fp32 MFMA)", 4.0 * B * T * T * Cc,
+                                 lambda: orig_attn(q, k, v, scale, exact, v_channel_major))
 
             E.PackedConv.__call__ = timed_call
             E.PackedConv.call_rec = timed_rec

@@ -312,6 +312,7 @@ int mdtile_gn_from_sums(const double* d_sums, double count, int BG, float* d_mea
  * ~1e-5 relative to fp32; it stages fragment-order copies of q, k, v in d_ws (mdtile_vae_attn_ws_size(B,C,T) bytes).
  * MDTILE_ATTN_EXACT_F32 (or env MDTILE_ATTN_MODE=f32) selects the exact-fp32 MFMA kernel, which needs no workspace. */
 #define MDTILE_ATTN_EXACT_F32 1
+#define MDTILE_ATTN_V_CHANNEL_MAJOR 2   /* v is [B,C,T] like q and k (split-bf16 kernel only): the v projection then runs on the same 1x1 kernels */
 size_t mdtile_vae_attn_ws_size(int B, int C, int T);
 int mdtile_vae_attn(const float* d_q, const float* d_k, const float* d_v, float* d_out, int B, int C, int T, float scale,
                     int flags, void* d_ws, mdtile_stream_t stream);

@@ -210,7 +210,7 @@ namespace mdt {
 bool attn_bf16x3_eligible(int C);
 size_t attn_bf16x3_ws_bytes(int B, int C, int Tq, int Tk);
 int attn_bf16x3_launch(const float* d_q, const float* d_k, const float* d_v_tok, float* d_out, int B, int C, int Tq, int Tk, float scale,
-                       void* d_ws, hipStream_t s);
+                       void* d_ws, hipStream_t s, bool v_channel_major = false);
 }  // namespace mdt
 
 static bool attn_force_f32() { return attn_strict_f32(); }
@@ -230,8 +230,9 @@ extern "C" int mdtile_vae_attn(const float* d_q, const float* d_k, const float* 
     hipStream_t s = as_stream(stream);
     if (!(flags & MDTILE_ATTN_EXACT_F32) && !attn_force_f32() && attn_bf16x3_eligible(C)) {
         MDT_CHECK_ARG(d_ws, "mdtile_vae_attn: the split-bf16 path needs the workspace of mdtile_vae_attn_ws_size()");
-        return attn_bf16x3_launch(d_q, d_k, d_v, d_out, B, C, T, T, scale, d_ws, s);
+        return attn_bf16x3_launch(d_q, d_k, d_v, d_out, B, C, T, T, scale, d_ws, s, (flags & MDTILE_ATTN_V_CHANNEL_MAJOR) != 0);
     }
+    MDT_CHECK_ARG(!(flags & MDTILE_ATTN_V_CHANNEL_MAJOR), "mdtile_vae_attn: the exact-fp32 kernel takes v token-major");
     dim3 grid((T + BM - 1) / BM, B), block(256);
     if (C == 512) hipLaunchKernelGGL(k_attn<4>, grid, block, 0, s, d_q, d_k, d_v, d_out, T, scale);
     else if (C == 256) hipLaunchKernelGGL(k_attn<2>, grid, block, 0, s, d_q, d_k, d_v, d_out, T, scale);

@@ -98,6 +98,39 @@ __global__ __launch_bounds__(256) void k_attn_prep_v(const float* __restrict__ s
     d[64 + lane] = lo;
 }
 
+// ---- prep: v  [C][T] fp32 CHANNEL-major (the layout every other 1x1 conv of the queue writes) -> the same records.  A lane owns one
+// channel and two runs of 4 consecutive keys: two 16-byte loads when T % 4 == 0 (rows then start 16-byte aligned).
+__global__ __launch_bounds__(256) void k_attn_prep_v_cm(const float* __restrict__ src, u32x4* __restrict__ dst, int C, int T, int groups) {
+    const int NMT = C / 32;
+    const size_t n = (size_t)groups * NMT * 64;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const int lane = (int)(idx & 63);
+    const int mt = (int)((idx >> 6) % NMT);
+    const int g = (int)((idx >> 6) / NMT);
+    const int b = blockIdx.y;
+    const int c = mt * 32 + (lane & 31);
+    const float* s = src + ((size_t)b * C + c) * T;
+    float v[8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int k0 = g * 16 + 8 * h + 4 * (lane >> 5);        // keys k0 .. k0 + 3 = record elements 4 h .. 4 h + 3
+        if ((T & 3) == 0) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k0 < T) t = *reinterpret_cast<const float4*>(s + k0);
+            v[4 * h] = t.x; v[4 * h + 1] = t.y; v[4 * h + 2] = t.z; v[4 * h + 3] = t.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[4 * h + i] = k0 + i < T ? s[k0 + i] : 0.0f;
+        }
+    }
+    u32x4 hi, lo;
+    split8v(v, hi, lo);
+    u32x4* d = dst + ((size_t)b * groups * NMT + (size_t)g * NMT + mt) * 128;
+    d[lane] = hi;
+    d[64 + lane] = lo;
+}
+
 // LDS-DMA of one 16-byte record per lane (global scalar base + 32-bit lane offset -> LDS wave-uniform base + 16 * lane), issued
 // through inline asm: hipcc books __builtin_amdgcn_global_load_lds as a pending FLAT access and then turns every later
 // `s_waitcnt lgkmcnt(N)` into lgkmcnt(0), which would serialise the fragment prefetch below (same finding as vae_conv_rec.hip).
@@ -483,7 +516,7 @@ size_t attn_bf16x3_ws_bytes(int B, int C, int Tq, int Tk) {
 }
 
 int attn_bf16x3_launch(const float* d_q, const float* d_k, const float* d_v_tok, float* d_out, int B, int C, int Tq, int Tk, float scale,
-                       void* d_ws, hipStream_t s) {
+                       void* d_ws, hipStream_t s, bool v_channel_major) {
     const int Tq128 = (Tq + 127) / 128 * 128, Tk128 = (Tk + 127) / 128 * 128;
     const size_t perq = (size_t)B * Tq128 * C * 4 / 16, perk = (size_t)B * Tk128 * C * 4 / 16;   // records per operand
     u32x4* Qr = (u32x4*)d_ws;
@@ -502,7 +535,8 @@ int attn_bf16x3_launch(const float* d_q, const float* d_k, const float* d_v_tok,
         const int groups = Tk128 / 16;
         const size_t n = (size_t)groups * (C / 32) * 64;
         dim3 grid(cdiv((long long)n, 256), B);
-        hipLaunchKernelGGL(k_attn_prep_v, grid, dim3(256), 0, s, d_v_tok, Vr, C, Tk, groups);
+        if (v_channel_major) hipLaunchKernelGGL(k_attn_prep_v_cm, grid, dim3(256), 0, s, d_v_tok, Vr, C, Tk, groups);
+        else hipLaunchKernelGGL(k_attn_prep_v, grid, dim3(256), 0, s, d_v_tok, Vr, C, Tk, groups);
     }
     MDT_LAUNCH_CHECK();
     const int nq8 = (Tq128 / BQ + 7) / 8 * 8;

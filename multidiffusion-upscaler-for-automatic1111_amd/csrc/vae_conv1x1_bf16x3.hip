@@ -211,6 +211,170 @@ __global__ __launch_bounds__(512, PXT == 128 ? 4 : 2) void k_conv1x1_bf16x3(cons
     }
 }
 
+// =====================================================================================================================
+// Streaming form for the wide images (round 3): the convs above are HBM-bound there (7.6 GB against 0.32 TFLOP for 256 -> 128 at 2224^2)
+// and moved their bytes with 4-byte-per-lane accesses in 0.5 .. 1 KB pieces per channel plane (3.4 - 3.6 TB/s).  Here
+//   * a block owns 512 consecutive pixels x 128 couts; a phase is ONE 16-channel K-step: 16 rows of 2 KB, each fetched by two
+//     back-to-back 1 KB LDS-DMA pieces (global_load_lds_dwordx4: 16 B per lane, no VGPRs, DRAM-page-sized runs per plane) into a
+//     3-stage ring of raw fp32 [16 ch][512 px] (32 KB per stage); the weights of the K-step (8 KB of pre-packed records) ride the same
+//     ring.  Two phases are in flight while one computes (the counted wait is vmcnt(5): every wave issues 4 + 1 pieces per phase);
+//   * the hi / lo split happens on the LDS -> register path (8 ds_read_b32 of one pixel's channels + the split per B fragment): the
+//     matrix pipe has time to spare here, the memory pipe has none;
+//   * the epilogue goes through an LDS transpose (the ring is free by then): every global store -- and every residual load -- is
+//     16 B per lane in 512-byte runs along a cout row, instead of 4 B per lane.
+// Needs H*W % 4 == 0 (16-byte rows), cin % 32 == 0, cout % 128 == 0; everything else stays on the kernel above.
+__device__ __forceinline__ void dma16s(const void* base, unsigned voff, const void* lds_dst) {
+    const unsigned l = (unsigned)(__UINTPTR_TYPE__)(const __attribute__((address_space(3))) void*)lds_dst;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(base), "s"(l)
+                 : "memory");
+}
+
+constexpr int S_NST = 3;
+
+// WM = waves along the couts (64 each): WM = 2 -> block of 128 couts x 512 px, WM = 4 -> 256 couts x 256 px (a conv with cout % 256 == 0
+// reads its input once).  Every wave owns 64 couts x 128 px = 2 x 4 accumulator tiles in both forms.
+template <int WM>
+__global__ __launch_bounds__(512, 2) void k_conv1x1_stream(const Conv1Params P) {
+    constexpr int MT = 2 * WM, WC = 8 / WM, NCOL = 4, SPX = 128 * WC;     // m-tiles, waves along the pixels, column tiles per wave, px per block
+    constexpr int S_IN_F = 16 * SPX;                  // floats per input stage ([16 ch][SPX])
+    constexpr int S_W_REC = 2 * MT * 64;              // weight records per K-step: [hl][mt][lane]
+    constexpr int IN_PW = (16 * SPX / 256) / 8;       // input DMA pieces (1 KB) per wave and phase: 4 / 2
+    constexpr int W_PW = (S_W_REC / 64) / 8;          // weight pieces per wave and phase: 1 / 2
+    static_assert(IN_PW + W_PW == (WM == 2 ? 5 : 4), "the counted vmcnt below");
+    // ring of raw fp32 input stages, then the weight ring; the epilogue's 8 wave-private transpose buffers (8 KB each) overlay the start
+    __shared__ __attribute__((aligned(16))) float smem[S_NST * S_IN_F + S_NST * S_W_REC * 4];
+    float* const in_l = smem;
+    u32x4* const w_l = reinterpret_cast<u32x4*>(smem + S_NST * S_IN_F);
+    static_assert(sizeof(smem) >= 8 * 8192, "transpose buffers");
+
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int ptile = (slot / P.NCB) * 8 + xcd, cb = slot % P.NCB;
+    if (ptile >= P.ptiles) return;
+    const int b = blockIdx.y;
+    const size_t p0 = (size_t)ptile * SPX;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kg = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wc = wave / WM;
+    const char* xb = reinterpret_cast<const char*>(P.x + (size_t)b * P.Cin * P.HW);
+    const int NP16 = P.NP * 2;                    // 16-channel K-steps
+
+    // DMA map of a stage: piece d = wave + 8 i -> channel d / (SPX / 256), 256-px part d % (SPX / 256); lanes past the end of the image
+    // re-read the row's last quad (never stored)
+    constexpr int PARTS = SPX / 256;
+    unsigned voff[IN_PW];
+#pragma unroll
+    for (int i = 0; i < IN_PW; ++i) {
+        const int d = wave + 8 * i;
+        size_t px = p0 + (size_t)(d % PARTS) * 256 + 4 * lane;
+        if (px > P.HW - 4) px = P.HW - 4;
+        voff[i] = (unsigned)(px * 4);
+    }
+    const u32x4* wsrc = P.w + (size_t)cb * P.NP * (2 * 2 * MT * 64);
+    auto issue = [&](int ph, int stage) {
+#pragma unroll
+        for (int i = 0; i < IN_PW; ++i) {
+            const int d = wave + 8 * i, c = d / PARTS;
+            dma16s(xb + (size_t)(ph * 16 + c) * P.HW * 4, voff[i], in_l + stage * S_IN_F + c * SPX + (d % PARTS) * 256);
+        }
+        // weights of K-step ph: packed as [phase32][hl][ks][mt][lane]; piece e = wave + 8 i -> hl = e / MT, m-tile e % MT
+#pragma unroll
+        for (int i = 0; i < W_PW; ++i) {
+            const int e = wave + 8 * i, hl = e / MT, mt = e % MT;
+            const u32x4* src = wsrc + ((size_t)((ph >> 1) * 2 + hl) * 2 + (ph & 1)) * (MT * 64) + mt * 64;
+            dma16s(src, lane * 16, w_l + stage * S_W_REC + hl * (MT * 64) + mt * 64);
+        }
+    };
+
+    f32x16 acc[2][NCOL];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NCOL; ++n)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[m][n][q] = 0.0f;
+
+    issue(0, 0);
+    if (NP16 > 1) issue(1, 1);
+    for (int ph = 0; ph < NP16; ++ph) {
+        const int stage = ph % S_NST;
+        // this wave's pieces in flight, oldest first: phase ph (IN_PW + W_PW), phase ph + 1 (IN_PW + W_PW)
+        if (ph + 1 < NP16) {
+            if (WM == 2) __builtin_amdgcn_s_waitcnt(0x0F75);       // vmcnt(5)
+            else __builtin_amdgcn_s_waitcnt(0x0F74);               // vmcnt(4)
+        } else {
+            __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (ph + 2 < NP16) issue(ph + 2, (ph + 2) % S_NST);        // the stage phase ph - 1 sat in: every wave is past its reads
+        const float* ist = in_l + stage * S_IN_F + (8 * kg) * SPX + wc * (NCOL * 32) + l31;
+        const u32x4* wst = w_l + stage * S_W_REC + (wm * 2) * 64 + lane;
+        bf16x8 a[2][2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int hl = 0; hl < 2; ++hl) a[m][hl] = __builtin_bit_cast(bf16x8, wst[hl * (MT * 64) + m * 64]);
+#pragma unroll
+        for (int n = 0; n < NCOL; ++n) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = ist[j * SPX + n * 32];
+            u32x4 hi, lo;
+            split8c(v, hi, lo);
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, hi), bl = __builtin_bit_cast(bf16x8, lo);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], bh, acc[m][n], 0, 0, 0);   // w_lo * x_hi
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], bl, acc[m][n], 0, 0, 0);   // w_hi * x_lo
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], bh, acc[m][n], 0, 0, 0);   // w_hi * x_hi
+            }
+        }
+    }
+    __syncthreads();          // every wave is done with the rings: their start becomes 8 wave-private transpose buffers of 8 KB
+
+    // epilogue: per (m-tile, cout half) pass the wave writes its 16 couts x 128 px to LDS ([16][128] fp32, one ds_write_b32 per value:
+    // lanes = consecutive pixels) and reads them back as float4 along the pixels: 512-byte runs per cout row for the residual loads
+    // and the stores.  C/D layout of a 32x32 MFMA: col = lane & 31, row = (q&3) + 8*(q>>2) + 4*(lane>>5).
+    float* T = smem + wave * 2048;
+    const size_t pw = p0 + (size_t)wc * (NCOL * 32);             // first pixel of this wave's 128
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int n = 0; n < NCOL; ++n)
+#pragma unroll
+                for (int qq = 0; qq < 8; ++qq) {
+                    const int q = 8 * half + qq;
+                    T[((q & 3) + 8 * ((q >> 2) & 1) + 4 * kg) * 128 + n * 32 + l31] = acc[m][n][q];
+                }
+            // rows of the pass: local row r (0..15) <-> cout cb*BM + (wm*2 + m)*32 + 16*half + r
+            const int cbase = cb * (MT * 32) + (wm * 2 + m) * 32 + 16 * half;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int f = lane + 64 * i, r = f >> 5, pq = f & 31;
+                const float4 t = *reinterpret_cast<const float4*>(T + r * 128 + 4 * pq);
+                const size_t px = pw + 4 * pq;
+                const int co = cbase + r;
+                if (px < P.HW) {
+                    const size_t o = ((size_t)b * P.Cout + co) * P.HW + px;
+                    const float bv = P.bias ? P.bias[co] : 0.0f;
+                    float4 o4 = make_float4(t.x + bv, t.y + bv, t.z + bv, t.w + bv);
+                    if (P.res) {
+                        const float4 r4 = *reinterpret_cast<const float4*>(P.res + o);
+                        o4.x += r4.x; o4.y += r4.y; o4.z += r4.z; o4.w += r4.w;
+                    }
+                    *reinterpret_cast<float4*>(P.y + o) = o4;
+                }
+            }
+        }
+    }
+}
+
 // OI fp32 -> records [cb][phase][hl][ks][mt][lane] of 8 bf16: cout = cb*BM + mt*32 + (lane & 31),
 // cin = phase*32 + ks*16 + (lane >> 5)*8 + j.  Zero outside [Cout).
 __global__ void k_conv1x1_pack_bf16x3(const float* __restrict__ w, u32x4* __restrict__ out, int Cout, int Cin, int MT, int NCB, int NP) {
@@ -248,6 +412,11 @@ static int conv1x1_mt(int cout) {
     static const bool mt8 = [] { const char* e = getenv("MDTILE_C1X1_MT8"); return !(e && e[0] == '0'); }();
     return cout > 128 && mt8 ? 8 : (cout > 64 ? 4 : 2);
 }
+// MDTILE_C1X1_STREAM=0 (probing, read per launch): keep the plain kernel on the wide images too
+static bool conv1x1_stream_on() {
+    const char* e = getenv("MDTILE_C1X1_STREAM");
+    return !(e && e[0] == '0');
+}
 
 size_t conv1x1_bf16x3_packed_floats(int cout, int cin) {
     const int MT = conv1x1_mt(cout), NCB = round_up1(cout, MT * 32) / (MT * 32), NP = cin / 32;
@@ -268,6 +437,17 @@ int conv1x1_bf16x3_launch(const float* d_x, const void* d_w_rec, const float* d_
     P.x = d_x; P.w = (const u32x4*)d_w_rec; P.bias = d_bias; P.res = d_res; P.y = d_y;
     P.B = B; P.Cin = cin; P.Cout = cout; P.HW = HW;
     const int MT = conv1x1_mt(cout);
+    if (MT >= 4 && cout % (MT * 32) == 0 && HW % 4 == 0 && HW >= 2048 && conv1x1_stream_on()) {
+        const int SPX = MT == 4 ? 512 : 256;
+        P.ptiles = (int)((HW + SPX - 1) / SPX);
+        P.NCB = cout / (MT * 32);
+        P.NP = cin / 32;
+        dim3 grid(((P.ptiles + 7) / 8) * 8 * P.NCB, B), block(512);
+        if (MT == 4) hipLaunchKernelGGL(k_conv1x1_stream<2>, grid, block, 0, s, P);
+        else hipLaunchKernelGGL(k_conv1x1_stream<4>, grid, block, 0, s, P);
+        MDT_LAUNCH_CHECK();
+        return MDTILE_OK;
+    }
     const int PXT = MT == 4 ? 128 : 256;
     P.ptiles = (int)((HW + PXT - 1) / PXT);
     P.NCB = round_up1(cout, MT * 32) / (MT * 32);

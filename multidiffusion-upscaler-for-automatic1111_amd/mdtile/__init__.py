@@ -25,6 +25,7 @@ BLEND_PARTIAL, BLEND_TILE_RANGE, BLEND_PACKED = 1, 2, 4
 CONV_UPSAMPLE2X = 1
 CONV_EXACT_F32 = 2
 ATTN_EXACT_F32 = 1
+ATTN_V_CHANNEL_MAJOR = 2
 MAX_BATCHES, MAX_REGIONS = 320, 16
 
 _DTYPES = {torch.float32: DT_F32, torch.float16: DT_F16, torch.bfloat16: DT_BF16}
@@ -772,20 +773,25 @@ class PackedConv:
         return y
 
 
-def vae_attn(q: torch.Tensor, k: torch.Tensor, v_tok: torch.Tensor, scale: float, exact: bool = False) -> torch.Tensor:
-    """Single-head attention core (tile_utils/attn.py:55-70).  q,k: [B,C,T]; v_tok: [B,T,C]; returns [B,C,T].
-    Default: split-bf16 matrix-core flash kernel (fp32 accumulate / softmax, ~1e-5 relative); exact=True: fp32 MFMA."""
+def vae_attn(q: torch.Tensor, k: torch.Tensor, v_tok: torch.Tensor, scale: float, exact: bool = False, v_channel_major: bool = False) -> torch.Tensor:
+    """Single-head attention core (tile_utils/attn.py:55-70).  q,k: [B,C,T]; v_tok: [B,T,C] (or [B,C,T] with v_channel_major); returns
+    [B,C,T].  Default: split-bf16 matrix-core flash kernel (fp32 accumulate / softmax, ~1e-5 relative); exact=True: fp32 MFMA."""
     _dev_tensor(q, "q", torch.float32)
     _dev_tensor(k, "k", torch.float32)
     _dev_tensor(v_tok, "v", torch.float32)
     B, C, T = q.shape
-    assert k.shape == q.shape and tuple(v_tok.shape) == (B, T, C)
+    assert k.shape == q.shape and tuple(v_tok.shape) == ((B, C, T) if v_channel_major else (B, T, C))
     out = torch.empty_like(q)
     ws_bytes = 0 if exact else lib().mdtile_vae_attn_ws_size(B, C, T)
     ws = torch.empty(max(1, (ws_bytes + 3) // 4), dtype=torch.float32, device=q.device)
-    _check(lib().mdtile_vae_attn(_p(q), _p(k), _p(v_tok), _p(out), B, C, T, scale, ATTN_EXACT_F32 if exact else 0, _p(ws), _stream()),
-           "mdtile_vae_attn")
+    flags = (ATTN_EXACT_F32 if exact else 0) | (ATTN_V_CHANNEL_MAJOR if v_channel_major else 0)
+    _check(lib().mdtile_vae_attn(_p(q), _p(k), _p(v_tok), _p(out), B, C, T, scale, flags, _p(ws), _stream()), "mdtile_vae_attn")
     return out
+
+
+def v_channel_major_ok() -> bool:
+    """True when vae_attn takes a channel-major v (the split-bf16 kernel; the exact-fp32 kernel wants it token-major)."""
+    return get_precision() == PRECISION_BF16X3
 
 
 def vae_attn_qk(q: torch.Tensor, k: torch.Tensor, v_tok: torch.Tensor, scale: float) -> torch.Tensor:

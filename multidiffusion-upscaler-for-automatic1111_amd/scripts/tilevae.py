@@ -79,8 +79,12 @@ class AttnPack:
         B, C, H, W = h.shape
         q = self.q(h).view(B, C, H * W)
         k = self.k(h).view(B, C, H * W)
-        v = self.v(h, token_major=True)
-        o = self.engine.vae_attn(q, k, v, float(int(C) ** (-0.5)))     # softmax(q^T k / sqrt(C)) v   (attn.py:55-67)
+        scale = float(int(C) ** (-0.5))
+        if getattr(self.engine, "v_channel_major_ok", lambda: False)():
+            # v like q and k: channel-major through the split-bf16 1x1 kernel; the attention prep reads it in that layout
+            o = self.engine.vae_attn(q, k, self.v(h).view(B, C, H * W), scale, v_channel_major=True)
+        else:
+            o = self.engine.vae_attn(q, k, self.v(h, token_major=True), scale)     # softmax(q^T k / sqrt(C)) v   (attn.py:55-67)
         return self.proj(o.view(B, C, H, W), residual=residual)        # proj_out + the queue's add_res
 
 

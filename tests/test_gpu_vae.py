@@ -85,6 +85,12 @@ CONV_CASES = [  # B, cin, cout, k, H, W, upsample, residual, token_major
     (1, 512, 512, 1, 31, 33, False, True, False),    # proj_out shape (+ the queue's residual add)
     (1, 32, 160, 1, 23, 29, False, True, False),     # split-bf16 1x1, ONE phase (no prefetch), 256-cout block variant with 160 real couts
     (1, 160, 320, 1, 10, 50, False, False, False),   # split-bf16 1x1, 5 phases (odd: the two-phase trip ends half way), 2 cout blocks of 256
+    (1, 64, 128, 1, 48, 52, False, True, False),     # streaming 1x1 (H*W % 4 == 0, >= 2048 px, cout % 128 == 0): 4 K-steps, ragged last 512-px block, residual
+    (2, 96, 256, 1, 50, 60, False, False, False),    # streaming 1x1: 6 K-steps (ring wraps twice), two cout blocks, batch 2
+    (1, 32, 128, 1, 40, 52, False, True, False),     # streaming 1x1: exactly two K-steps (no steady-state issue)
+    (1, 512, 128, 1, 64, 64, False, False, False),   # streaming 1x1: 32 K-steps
+    (1, 64, 512, 1, 40, 64, False, True, False),     # streaming 1x1, 256-cout blocks x 2, residual
+    (1, 64, 128, 1, 45, 47, False, True, False),     # H*W % 4 != 0: stays on the plain 1x1 kernel
 ]
 
 
@@ -423,3 +429,17 @@ def test_downsample_conv_vs_torch(plugin, cuda, B, cin, cout, H, W, exact):
     assert out.shape == ref.shape
     err = _rel(out, ref)
     assert err < (2e-5 if exact else 5e-5), f"downsample conv rel err {err}"
+
+
+@pytest.mark.parametrize("B,C,T", [(1, 512, 3000), (2, 256, 700), (1, 128, 2050), (1, 512, 77)])
+def test_attention_channel_major_v_equals_token_major(plugin, cuda, B, C, T):
+    """MDTILE_ATTN_V_CHANNEL_MAJOR: v handed over as [B, C, T] (what the split-bf16 1x1 kernels write) must give the SAME records, hence
+    bit-identical attention output, as the token-major form -- T % 4 == 0 (float4 rows) and ragged T."""
+    E = plugin.engine
+    torch.manual_seed(T + C)
+    q, k = torch.randn(B, C, T, device=cuda), torch.randn(B, C, T, device=cuda) * 1.3
+    v = torch.randn(B, C, T, device=cuda)
+    scale = float(C ** -0.5)
+    a = E.vae_attn(q, k, v.permute(0, 2, 1).contiguous(), scale)
+    b = E.vae_attn(q, k, v, scale, v_channel_major=True)
+    assert torch.equal(a, b)

@@ -90,7 +90,7 @@ def test_dma_protocol_in_the_device_assembly():
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asm_guard.py")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout
-    assert r.stdout.count(" ok") == 6, r.stdout
+    assert r.stdout.count(" ok") == 8, r.stdout
 
 
 def test_no_cpu_fallback(built_lib):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Build-time guard for the hand-counted LDS-DMA protocol of the record conv / attention kernels (csrc/vae_conv_rec.hip: dma16,
-csrc/vae_attn_bf16x3.hip: dma16a).  The kernels issue `global_load_lds_dwordx4` from inline asm (hipcc would book the builtin as a
+"""Build-time guard for the hand-counted LDS-DMA protocol of the record conv / attention / streaming 1x1 kernels (csrc/vae_conv_rec.hip:
+dma16, csrc/vae_attn_bf16x3.hip: dma16a, csrc/vae_conv1x1_bf16x3.hip: dma16s).  The kernels issue `global_load_lds_dwordx4` from inline asm (hipcc would book the builtin as a
 FLAT access and degrade every later lgkmcnt wait) and count its completion by hand: M0 is saved, loaded with the LDS destination,
 `s_nop 2`, the DMA, M0 restored; every consumer sits behind `s_waitcnt vmcnt(0)` (or the one counted `vmcnt(5)`) + `s_barrier`.
 A compiler upgrade that re-orders or drops any of that would only show up as wrong pixels; this script compiles the two files to
@@ -75,14 +75,19 @@ def check_kernel(name: str, ins: list, expect: dict) -> list:
     bars = [k for k, l in enumerate(ins) if l.startswith("s_barrier")]
     bar_waits = []
     for k in bars:
-        j = k - 1
-        while j >= 0 and re.match(r"s_(mov|add|and|or|lshl|lshr|mul|cmp|cselect|sub|ashr|bfe|nop|xor|not|max|min|addc|bitcmp)", ins[j]):
+        # walk back over scalar ALU and branches: a wait selected by a (wave-uniform) branch sits in its own basic block in front of
+        # the barrier's block, e.g.  s_waitcnt vmcnt(0) / loop header / s_cbranch / s_waitcnt vmcnt(5) / s_barrier
+        j, found = k - 1, []
+        while j >= 0 and (re.match(r"s_(mov|add|and|or|lshl|lshr|mul|cmp|cselect|sub|ashr|bfe|nop|xor|not|max|min|addc|bitcmp|cbranch|branch|waitcnt)", ins[j])):
+            if ins[j].startswith("s_waitcnt"):
+                found.append(ins[j])
             j -= 1
-        if not (j >= 0 and ins[j].startswith("s_waitcnt")):
+        if not found:
             errs.append(f"s_barrier at {k} is not preceded by an s_waitcnt (found {ins[max(0, j)]})")
             continue
-        m = re.search(r"vmcnt\((\d+)\)", ins[j])
-        bar_waits.append(int(m.group(1)) if m else None)      # None: an lgkmcnt-only wait (LDS hand-over, no DMA consumed behind it)
+        for w in found:
+            m = re.search(r"vmcnt\((\d+)\)", w)
+            bar_waits.append(int(m.group(1)) if m else None)      # None: an lgkmcnt-only wait (LDS hand-over, no DMA consumed behind it)
     counted = {w for w in bar_waits if w is not None}
     n_mfma = sum(1 for l in ins if l.startswith("v_mfma_f32_32x32x16_bf16"))
     for key, val in expect.items():
@@ -101,7 +106,10 @@ def main() -> int:
     errs = []
     rec = kernels(device_asm(os.path.join(CSRC, "vae_conv_rec.hip")))
     att = kernels(device_asm(os.path.join(CSRC, "vae_attn_bf16x3.hip")))
+    c11 = kernels(device_asm(os.path.join(CSRC, "vae_conv1x1_bf16x3.hip")))
     plan = [
+        (c11, "k_conv1x1_streamILi2", dict(dma_min=5, barrier_vmcnt=[0, 5], mfma_multiple=24)),
+        (c11, "k_conv1x1_streamILi4", dict(dma_min=4, barrier_vmcnt=[0, 4], mfma_multiple=24)),
         (rec, "k_conv3x3_recILi2ELi2ELi4", dict(dma_min=8, barrier_vmcnt=[0, 5], mfma_multiple=12)),
         (rec, "k_conv3x3_recILi1ELi1ELi2", dict(dma_min=4, barrier_vmcnt=[0, 5], mfma_multiple=3)),
         (rec, "k_upconv_rec", dict(dma_min=8, barrier_vmcnt=[0], mfma_multiple=12)),
