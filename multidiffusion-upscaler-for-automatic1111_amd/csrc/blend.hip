@@ -420,25 +420,16 @@ __global__ __launch_bounds__(256) void k_gather_rect(const T* __restrict__ x_in,
 }
 
 // (planes per thread, candidates per chunk).  PP must divide N*C; MDTILE_BLEND_CFG="PP,G" overrides the default (probing).
-// Residency throttle (probing, MDTILE_BLEND_LDS=bytes): the kernel uses no LDS; a dynamic allocation only limits how many blocks a CU
-// holds at once.  With every block of the grid resident at the same time the launch runs as ONE wave front -- all reads, then all
-// writes -- and the two HBM directions never overlap; fewer resident blocks make later blocks start while earlier ones store.
-static unsigned blend_lds_bytes(long long blocks) {
-    if (const char* e = getenv("MDTILE_BLEND_LDS")) return (unsigned)atoi(e);
-    return 0;
-}
-
 template <typename T, int PP, int G>
 void launch_blend_cfg(const BlendParams& P, int method, hipStream_t s) {
     dim3 grid(cdiv((long long)P.nrows * ((P.W + 3) / 4), 256), (P.N * P.C) / PP), block(256);
     const bool packed = (P.flags & MDTILE_BLEND_PACKED) != 0;
-    const unsigned lds = blend_lds_bytes((long long)grid.x * grid.y);
     if (method == MDTILE_METHOD_MD) {
-        if (packed) hipLaunchKernelGGL((k_blend<T, MDTILE_METHOD_MD, PP, G, true>), grid, block, lds, s, P);
-        else hipLaunchKernelGGL((k_blend<T, MDTILE_METHOD_MD, PP, G, false>), grid, block, lds, s, P);
+        if (packed) hipLaunchKernelGGL((k_blend<T, MDTILE_METHOD_MD, PP, G, true>), grid, block, 0, s, P);
+        else hipLaunchKernelGGL((k_blend<T, MDTILE_METHOD_MD, PP, G, false>), grid, block, 0, s, P);
     } else {
-        if (packed) hipLaunchKernelGGL((k_blend<T, MDTILE_METHOD_MOD, PP, G, true>), grid, block, lds, s, P);
-        else hipLaunchKernelGGL((k_blend<T, MDTILE_METHOD_MOD, PP, G, false>), grid, block, lds, s, P);
+        if (packed) hipLaunchKernelGGL((k_blend<T, MDTILE_METHOD_MOD, PP, G, true>), grid, block, 0, s, P);
+        else hipLaunchKernelGGL((k_blend<T, MDTILE_METHOD_MOD, PP, G, false>), grid, block, 0, s, P);
     }
 }
 

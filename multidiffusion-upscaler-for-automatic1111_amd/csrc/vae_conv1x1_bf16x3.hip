@@ -407,11 +407,8 @@ inline int round_up1(int v, int m) { return (v + m - 1) / m * m; }
 namespace mdt {
 
 bool conv1x1_bf16x3_eligible(int cout, int cin) { return cin % 32 == 0 && cout >= 32; }
-static int conv1x1_mt(int cout) {
-    // MDTILE_C1X1_MT8=0 (probing, read once: packing and launch must agree): 128-cout blocks also for wider convs
-    static const bool mt8 = [] { const char* e = getenv("MDTILE_C1X1_MT8"); return !(e && e[0] == '0'); }();
-    return cout > 128 && mt8 ? 8 : (cout > 64 ? 4 : 2);
-}
+// couts per block: 256 (one pass over the input for cout % 256 == 0), 128, or 64 for the small decoders' narrow convs
+static int conv1x1_mt(int cout) { return cout > 128 ? 8 : (cout > 64 ? 4 : 2); }
 // MDTILE_C1X1_STREAM=0 (probing, read per launch): keep the plain kernel on the wide images too
 static bool conv1x1_stream_on() {
     const char* e = getenv("MDTILE_C1X1_STREAM");

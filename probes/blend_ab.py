@@ -33,13 +33,5 @@ if "--data" in sys.argv:
 for cfg in ("0,0", "8,2", "8,4", "4,2", "4,4", "2,4"):
     os.environ["MDTILE_BLEND_CFG"] = cfg
     run(f"cfg {cfg}")
-
-# residency throttle: a dynamic LDS allocation the kernel never touches limits the resident blocks per CU (160 KB / bytes), so that
-# the grid runs in several staggered rounds and the stores of early blocks overlap the loads of late ones
-for cfg in ("8,2", "4,2", "4,4", "2,4"):
-    for lds in (0, 40960, 54272, 65536):
-        os.environ["MDTILE_BLEND_CFG"] = cfg
-        os.environ["MDTILE_BLEND_LDS"] = str(lds)
-        run(f"cfg {cfg} lds {lds:6d} ({'all resident' if lds == 0 else str(163840 // lds) + ' blocks / CU'})")
-os.environ.pop("MDTILE_BLEND_LDS", None)
-os.environ["MDTILE_BLEND_CFG"] = "0,0"
+# (round 3: a residency throttle -- fewer resident blocks per CU through an unused dynamic LDS allocation, so that late blocks load while early
+# ones store -- was A/B'd here and measured slower in every configuration, profiles/r3b/blend_ab_residency_throttle.log; the knob is gone)
