@@ -63,7 +63,7 @@ def _free_port() -> int:
     return port
 
 
-def _worker(rank, world, port, fast, q):
+def _worker(rank, world, port, fast, q, hw=(40, 56)):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -72,7 +72,7 @@ def _worker(rank, world, port, fast, q):
         from oracle import ldm_decoder as ld, vae_oracle as vo
         dec = ld.make_decoder(0, small=True)
         torch.manual_seed(2)
-        z = torch.randn(1, 4, 40, 56)
+        z = torch.randn(1, 4, *hw)
         hook = _hook(dec, 16, True, fast)
         hook.shard = (rank, world)
         hook.gather_to = 0          # rank 0 returns the assembled image (one grouped exchange of the tile rectangles)
@@ -82,9 +82,9 @@ def _worker(rank, world, port, fast, q):
         if rank == 0:
             err = (out - ref).abs().max().item() / ref.abs().max().item()
             assert err < 2e-4, f"assembled image on rank 0: rel err {err}"
-        ins, outs = vo.split_tiles(40, 56, 16, True)
+        ins, outs = vo.split_tiles(hw[0], hw[1], 16, True)
         mine = list(range(rank, len(ins), world))
-        assert mine, "test geometry must give every rank a tile"
+        assert mine or hw != (40, 56), "the default geometry must give every rank a tile"
         for i in mine:
             ob = outs[i]
             a, b = out[:, :, ob[2]:ob[3], ob[0]:ob[1]], ref[:, :, ob[2]:ob[3], ob[0]:ob[1]]
@@ -106,6 +106,25 @@ def test_sharded_decode_over_gloo(world, fast):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, fast, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    bad = [f"rank {r}: {msg}" for r, msg in results if msg != "ok"]
+    assert not bad, "\n".join(bad)
+
+
+@pytest.mark.parametrize("fast", [True, False])
+def test_sharded_decode_with_a_rank_that_owns_no_tile(fast):
+    """Two tiles over three ranks: rank 2 decodes nothing but still takes part in the sequence-parallel estimator / the pooled-statistics
+    exchange, and rank 0 still ends with the assembled image."""
+    from oracle import vae_oracle as vo
+    assert len(vo.split_tiles(40, 30, 16, True)[0]) == 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 3, port, fast, q, (40, 30))) for r in range(3)]
     for p in procs:
         p.start()
     results = [q.get(timeout=600) for _ in procs]
