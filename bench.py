@@ -564,7 +564,7 @@ def main():
             "metric": "latent-px/sec tile-blend+VAE-decode, 8K image", "value": round(value, 1), "unit": "latent-px/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32" if E.get_precision() == E.PRECISION_F32 else "bf16x3+f32", "data": "synthetic",
-            "config": {"workload": f"SDXL 8192x8192 (latent {L}x{L}): {args.evals} x [tile gather + {'MultiDiffusion' if args.method == 'md' else 'Mixture-of-Diffusers'} "
+            "config": {"workload": f"{'SDXL ' if L == 1024 else ''}{8 * L}x{8 * L} (latent {L}x{L}): {args.evals} x [tile gather + {'MultiDiffusion' if args.method == 'md' else 'Mixture-of-Diffusers'} "
                                    f"blend, {plan.num_tiles} tiles {plan.tile_w}x{plan.tile_h} overlap {plan.overlap}, N=2,C=4] + "
                                    + ("no VAE" if hook is None else f"tiled VAE decode (tile {args.vae_tile}, {'slow' if args.slow_vae else 'fast'} mode, SD decoder ch=128, random weights)"),
                        "latent": [L, L], "tile": [plan.tile_w, plan.tile_h], "overlap": plan.overlap, "evals": args.evals,
