@@ -195,14 +195,18 @@ def test_attention_vs_oracle(plugin, cuda, B, C, T, exact):
 
 
 @pytest.mark.parametrize("exact", [False, True], ids=["bf16x3", "f32"])
-def test_attention_online_softmax_rescale_branch(plugin, cuda, exact):
+@pytest.mark.parametrize("C,T,spike", [(128, 300, 4.0), (128, 300, 1.0), (512, 700, 2.5), (512, 700, 0.6), (256, 1500, 3.0)])
+def test_attention_online_softmax_rescale_branch(plugin, cuda, exact, C, T, spike):
     """Force the running-max update late in the key sequence (a spike in the last key block) -- bounded random data alone
-    never exercises a wrong rescale."""
+    never exercises a wrong rescale.  The split-bf16 kernel takes a key block's exponentials against the maximum as of the PREVIOUS
+    block: the large spikes (> 2^60 over the reference in the log2 domain) go through its redo path in a late block, the small ones
+    through the deferred rescale."""
     E = plugin.engine
     torch.manual_seed(0)
-    B, C, T = 1, 128, 300
+    B = 1
     q, k, v = torch.randn(B, C, T), torch.randn(B, C, T), torch.randn(B, C, T)
-    k[:, :, 290] = q[:, :, 5] * 4.0      # query 5 matches key 290 very strongly
+    k[:, :, T - 10] = q[:, :, 5] * spike      # query 5 matches a key of the last block very strongly
+    k[:, :, T // 2] = q[:, :, 170] * spike * 0.8
     k[:, :, 3] = q[:, :, 170] * 3.0
     scale = float(C ** -0.5)
     w_ = torch.softmax(torch.bmm(q.permute(0, 2, 1), k) * scale, dim=2)
