@@ -359,9 +359,11 @@ def main():
                     tag = "k_conv3x3_bf16x3<*> (fp32 hand-over)" if bf else "k_conv<3,*> (exact fp32 MFMA)"
                 return prof.wrap(tag, flops, lambda: orig_call(self, x, residual, upsample2x, token_major, exact, pre_gn))
 
-            def timed_rec(self, x, residual=None, upsample2x=False, want_f32=True, want_rec=False, rec_coef=None):
+            def timed_rec(self, x, residual=None, upsample2x=False, want_f32=True, want_rec=False, rec_coef=None, window=None):
                 # record kernels: the tag IS the kernel symbol mdtile_conv2d_rec launches (csrc/vae_conv_rec.hip, dispatch at the end)
                 B, cin, H, W = x.shape
+                if window is not None:
+                    H, W = window[2], window[3]      # live-window narrowing: the flops EXECUTED are those of the window
                 if upsample2x:
                     H, W = 2 * H, 2 * W
                 flops = 2.0 * B * H * W * self.cout * cin * 9
@@ -369,7 +371,7 @@ def main():
                 if upsample2x:
                     flops *= 4.0 / 9.0
                     tag = "k_upconv_rec"
-                return prof.wrap(tag, flops, lambda: orig_rec(self, x, residual, upsample2x, want_f32, want_rec, rec_coef))
+                return prof.wrap(tag, flops, lambda: orig_rec(self, x, residual, upsample2x, want_f32, want_rec, rec_coef, window))
 
             orig_attn = E.vae_attn
 

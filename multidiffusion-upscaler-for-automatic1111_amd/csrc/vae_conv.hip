@@ -243,7 +243,7 @@ size_t rec_image_bytes(int B, int C, int H, int W);
 int rec_from_f32_launch(const float* d_x, const float* d_coef, void* d_rec, int B, int C, int H, int W, hipStream_t s);
 int rec_to_f32_launch(const void* d_rec, float* d_x, int B, int C, int H, int W, hipStream_t s);
 int conv_rec_launch(const void* d_xrec, const void* d_w_rec, const float* d_bias, const float* d_res, float* d_y32, void* d_yrec,
-                    const float* d_ycoef, int B, int cin, int cout, int H, int W, int up, hipStream_t s);
+                    const float* d_ycoef, int B, int cin, int cout, int H, int W, int up, hipStream_t s, const int* win4 = nullptr);
 // vae_conv1x1_bf16x3.hip
 bool conv1x1_bf16x3_eligible(int cout, int cin);
 size_t conv1x1_bf16x3_packed_floats(int cout, int cin);
@@ -368,6 +368,21 @@ extern "C" int mdtile_conv2d_rec(const void* d_x_rec, const float* d_w_packed, c
                   "mdtile_conv2d_rec: the narrow (cout < 32) kernel writes fp32 only, no residual, no upsample (cout=%d)", cout);
     return conv_rec_launch(d_x_rec, d_w_packed + f32_packed_floats(cout, cin, 3), d_bias, d_residual, d_y, d_y_rec, d_y_coef, B, cin, cout,
                            H, W, up, as_stream(stream));
+}
+
+// Nearest-2x + 3x3 conv of a WINDOW of the input record image (live-window narrowing of the decoder tiles, see include/mdtile.h)
+extern "C" int mdtile_upconv2d_rec_window(const void* d_x_rec, const float* d_w_packed, const float* d_bias, float* d_y, void* d_y_rec,
+                                          const float* d_y_coef, int B, int cin, int cout, int Hin, int Win, int y0, int x0, int h, int w,
+                                          mdtile_stream_t stream) {
+    MDT_CHECK_ARG(d_x_rec && d_w_packed && (d_y || d_y_rec), "mdtile_upconv2d_rec_window: null argument (one of d_y / d_y_rec is required)");
+    MDT_CHECK_ARG(mdtile_conv2d_rec_supported(cout, cin, 3, 0) && cout % 128 == 0, "mdtile_upconv2d_rec_window: no record kernel for cout=%d cin=%d", cout, cin);
+    MDT_CHECK_ARG(h >= 1 && w >= 1 && y0 >= 0 && x0 >= 0 && y0 + h <= Hin && x0 + w <= Win,
+                  "mdtile_upconv2d_rec_window: window y0=%d x0=%d h=%d w=%d leaves the %dx%d input", y0, x0, h, w, Hin, Win);
+    MDT_CHECK_ARG(rec_image_ok(B, cin, Hin, Win) && rec_image_ok(B, cout, 2 * h, 2 * w),
+                  "mdtile_upconv2d_rec_window: unsupported shape B=%d cin=%d cout=%d Hin=%d Win=%d", B, cin, cout, Hin, Win);
+    const int win4[4] = {Hin, Win, y0, x0};
+    return conv_rec_launch(d_x_rec, d_w_packed + f32_packed_floats(cout, cin, 3), d_bias, nullptr, d_y, d_y_rec, d_y_coef, B, cin, cout,
+                           2 * h, 2 * w, 1, as_stream(stream), win4);
 }
 
 // ldm Downsample: y = conv3x3_stride2(pad(x, right 1, bottom 1)); output (Hin - 2) / 2 + 1 rows (likewise columns).

@@ -52,6 +52,7 @@ struct ConvRParams {
     const float* coef;   // activation of the record output: [B][2][Cout] = (a, s), yrec = split(silu(a y + s)); null = split(y)
     int B, Cin, Cout, H, W;   // H, W: OUTPUT size
     int Hin, Win;             // input size (= H, W; half of it for the sub-pixel upsample kernel)
+    int HinF, WinF, iy0, ix0; // sub-pixel upsample kernel: the input is the window [iy0 : iy0 + Hin, ix0 : ix0 + Win] of a record image of HinF x WinF px
     int ptiles, PX, NCB, NK;  // pixel tiles, tiles per row, cout blocks, 16-channel K-steps
 };
 
@@ -486,11 +487,11 @@ __global__ __launch_bounds__(512, 2) void k_upconv_rec(const ConvRParams P) {
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kg = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wr = wave / WM;
-    const int Hp = P.Hin + 2, Wp = P.Win + 2, Pn = P.Cin >> 3;
+    const int Hp = P.HinF + 2, Wp = P.WinF + 2, Pn = P.Cin >> 3;      // pitches of the WHOLE input image; items tile its window
     const size_t plane = (size_t)Hp * Wp;
 
     struct Item {
-        int b, cb, a, y0, x0;   // y0, x0: INPUT coordinates
+        int b, cb, a, y0, x0;   // y0, x0: INPUT coordinates (relative to the window)
     };
     const int per = P.NCB * 2, per_img = ((P.ptiles + 7) / 8) * 8 * per, total = per_img * P.B;
     auto decode = [&](int work, Item& it) -> bool {
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(512, 2) void k_upconv_rec(const ConvRParams P) {
             if (s >= IS::HALF) s = IS::HALF - 1;
             const int g = s / (ROWS * COLS), p = s - g * (ROWS * COLS);
             const int r = p / COLS, c = p - r * COLS;
-            int pr = it.y0 + r, pc = it.x0 + c;
+            int pr = P.iy0 + it.y0 + r, pc = P.ix0 + it.x0 + c;     // inside the window's own border: the image's real neighbours
             pr = pr < Hp ? pr : Hp - 1;
             pc = pc < Wp ? pc : Wp - 1;
             ioff[i] = (unsigned)(((size_t)g * plane + (size_t)pr * Wp + pc) * 16);
@@ -777,13 +778,17 @@ int rec_to_f32_launch(const void* d_rec, float* d_x, int B, int C, int H, int W,
     return MDTILE_OK;
 }
 
+// win4 (sub-pixel upsample kernel only, else null): {HinF, WinF, iy0, ix0} -- d_xrec is the record image of [B, cin, HinF, WinF] and the conv
+// reads its window [iy0 : iy0 + H/2, ix0 : ix0 + W/2]
 int conv_rec_launch(const void* d_xrec, const void* d_w_rec, const float* d_bias, const float* d_res, float* d_y32, void* d_yrec,
-                    const float* d_ycoef, int B, int cin, int cout, int H, int W, int up, hipStream_t s) {
+                    const float* d_ycoef, int B, int cin, int cout, int H, int W, int up, hipStream_t s, const int* win4) {
     ConvRParams P;
     P.x = (const u32x4*)d_xrec; P.w = (const u32x4*)d_w_rec; P.bias = d_bias; P.res = d_res; P.y32 = d_y32;
     P.yrec = (u32x4*)d_yrec; P.coef = d_ycoef;
     P.B = B; P.Cin = cin; P.Cout = cout; P.H = H; P.W = W;
     P.Hin = up ? H / 2 : H; P.Win = up ? W / 2 : W;
+    P.HinF = win4 ? win4[0] : P.Hin; P.WinF = win4 ? win4[1] : P.Win;
+    P.iy0 = win4 ? win4[2] : 0; P.ix0 = win4 ? win4[3] : 0;
     P.NCB = cout % 128 == 0 ? cout / 128 : 1;
     P.NK = cin / 16;
     if (up) {

@@ -39,6 +39,8 @@ FUSE_PRE_GN = _os.environ.get("MDTILE_FUSE_GN", "1") != "0"
 # conv writes already normalised + SiLU'd (engine: mdtile_conv2d_rec); MDTILE_REC=0 keeps the fp32 hand-over (A/B, debugging)
 TILE_BATCH = int(_os.environ.get("MDTILE_TILE_BATCH", "3"))     # fast mode: tiles of equal shape per sweep (see vae_tile_forward)
 REC_PATH = _os.environ.get("MDTILE_REC", "1") != "0"
+# fast-mode decoder tiles shed their dead border where the resolution doubles (live_windows below); 0 = decode the whole padded tile
+LIVE_WINDOW = _os.environ.get("MDTILE_LIVE_WINDOW", "1") != "0"
 # multi-GPU fast mode: run the GroupNorm estimator sequence-parallel across the ranks (mdtile/seqpar.py); 0 = every rank
 # repeats the whole estimator (no communication, but 1 of every rank's ~3 work units at 8 GPUs)
 SP_ESTIMATOR = _os.environ.get("MDTILE_SP_ESTIMATOR", "1") != "0"
@@ -171,6 +173,57 @@ def crop_valid_region(x, input_bbox, target_bbox, is_decoder):
     padded = [i * 8 if is_decoder else i // 8 for i in input_bbox]
     m = [target_bbox[i] - padded[i] for i in range(4)]
     return x[:, :, m[2]:x.size(2) + m[3], m[0]:x.size(3) + m[1]]
+
+
+def live_windows(steps: List["Step"], tile_hw: Tuple[int, int], valid: Tuple[int, int, int, int]):
+    """Live-window narrowing of ONE decoder tile whose GroupNorm statistics are all frozen (fast mode).
+
+    Upstream decodes the whole padded tile and crop_valid_region (:248-259, applied at :630-632) keeps `valid` (y0, x0, y1, x1 in latent
+    px relative to the tile; the padding -- 11 latent px for the decoder, :371 -- is thrown away).  With frozen statistics every layer
+    behind the attention is local (3x3 convs, 1x1 convs, pointwise norm / SiLU, nearest 2x), so an output pixel further than the number
+    of 3x3 convs still to come from the valid region cannot reach it and need not be computed.  The plane is narrowed where it is
+    cheapest, at the upsample convs: walking the program backwards, `need` counts the 3x3 convs behind a point in pixels of that
+    level; at the upsample conv that opens a level of `scale` px per latent px the plane becomes `valid` grown by
+    ceil(need / scale) latent px (whole latent px: the tile's own crop and store stay in latent units), clamped to the tile, and
+    the level below has to provide that window halved plus the conv's own 1 px halo (read from the un-narrowed input image, so
+    it holds the true neighbours).  A narrowed plane is a zero-padded image of its own: its errors creep inwards one pixel per
+    conv and stop exactly at the valid region.  The walk ends at the attention (it needs every token of the tile).
+    SD decoder (3 resblocks per level, conv_out): grow = 1, 3, 7 latent px for the 8x, 4x, 2x levels; the 1x level stays whole.
+
+    Returns ({index of the upsample step: (y0, x0, h, w) window of ITS input plane, in input px}, final rect in latent px relative to
+    the tile (y0, x0, y1, x1)) -- ({}, whole tile) when nothing can be shed."""
+    th, tw = tile_hw
+    whole = (0, 0, th, tw)
+    ups = [i for i, s in enumerate(steps) if s.kind == "conv" and s.upsample]
+    if not ups or any(s.kind == "conv" and s.downsample for s in steps):
+        return {}, whole
+    scale, need, grow = 1 << len(ups), 0, {}
+    for i in range(len(steps) - 1, -1, -1):
+        s = steps[i]
+        if s.kind == "attn":
+            break
+        if s.kind != "conv":
+            continue                       # frozen norm, SiLU, residual bookkeeping (+ 1x1 nin_shortcut), tanh: pointwise
+        ks = int(getattr(s.conv, "ksize", 3))
+        if s.upsample:
+            m = -(-need // scale)          # whole latent px
+            grow[i] = m
+            scale //= 2
+            need = m * scale + (ks // 2)
+        else:
+            need += ks // 2
+    vy0, vx0, vy1, vx1 = valid
+    windows, cur, in_scale = {}, whole, 1
+    for i in ups:
+        if i in grow:
+            m = grow[i]
+            rect = (max(cur[0], vy0 - m), max(cur[1], vx0 - m), min(cur[2], vy1 + m), min(cur[3], vx1 + m))
+            if rect != cur:
+                windows[i] = ((rect[0] - cur[0]) * in_scale, (rect[1] - cur[1]) * in_scale,
+                              (rect[2] - rect[0]) * in_scale, (rect[3] - rect[1]) * in_scale)
+                cur = rect
+        in_scale *= 2
+    return windows, cur
 
 
 class GroupNormParam:
@@ -316,10 +369,11 @@ class VAEHook:
             return need_f32, "raw"
         return True, None
 
-    def _run_tile_rec(self, steps: List[Step], x: Tensor, frozen, coefs, norm_ord) -> Tensor:
+    def _run_tile_rec(self, steps: List[Step], x: Tensor, frozen, coefs, norm_ord, windows=None) -> Tensor:
         """One tile start to finish with frozen statistics (upstream's single sweep, :578-642).  A 3x3 conv that the record
         kernels take reads its input as a record image; whoever produces that input writes it in that form -- the previous
-        record conv's epilogue (norm + SiLU + split fused), or mdtile_rec_from_f32 behind conv_in / attention."""
+        record conv's epilogue (norm + SiLU + split fused), or mdtile_rec_from_f32 behind conv_in / attention.
+        windows (live_windows): the upsample convs listed there compute only that window of their input plane."""
         E = self.engine
         res: List[Tensor] = []
         xrec, pre = None, None
@@ -348,8 +402,9 @@ class VAEHook:
                         if xrec is None:
                             xrec = E.rec_from_f32(x, None)
                         need_f32, rk = self._demand(steps, i)
+                        win = windows.get(i) if windows else None
                         x, xrec = s.conv.call_rec(xrec, residual=residual, upsample2x=s.upsample, want_f32=need_f32, want_rec=rk is not None,
-                                                  rec_coef=None if rk in (None, "raw") else coefs[norm_ord[rk]])
+                                                  rec_coef=None if rk in (None, "raw") else coefs[norm_ord[rk]], **({"window": win} if win else {}))
                     else:
                         x, xrec = s.conv(x, residual=residual, upsample2x=s.upsample, pre_gn=pre), None
                 pre = None
@@ -358,6 +413,21 @@ class VAEHook:
             elif s.kind == "tanh":
                 x = E.tanh(x)
         return x
+
+    def _live_plan(self, steps: List[Step], in_bbox, out_bbox):
+        """(windows, narrowed input bbox) of one decoder tile for _run_tile_rec / crop_store -- ({}, in_bbox) when live-window narrowing does
+        not apply (switched off, encoder, an upsample conv outside the record kernels)."""
+        if not (LIVE_WINDOW and self.is_decoder):
+            return {}, tuple(in_bbox)
+        if not all(self._takes_rec(s) for s in steps if s.kind == "conv" and s.upsample):
+            return {}, tuple(in_bbox)
+        x1, x2, y1, y2 = in_bbox
+        ox1, ox2, oy1, oy2 = out_bbox
+        if any(v % 8 for v in (ox1, ox2, oy1, oy2)):
+            return {}, tuple(in_bbox)
+        valid = (oy1 // 8 - y1, ox1 // 8 - x1, oy2 // 8 - y1, ox2 // 8 - x1)
+        windows, (ry0, rx0, ry1, rx1) = live_windows(steps, (y2 - y1, x2 - x1), valid)
+        return windows, (x1 + rx0, x1 + rx1, y1 + ry0, y1 + ry1)
 
     def _apply_norm(self, steps: List[Step], st: TileState, var: Tensor, mean: Tensor):
         E = self.engine
@@ -457,12 +527,13 @@ class VAEHook:
             with torch.cuda.device(d):
                 b = in_bboxes[i]
                 x = E.gather_rect(L["z"], b[0], b[2], b[1] - b[0], b[3] - b[2])
-                x = self._run_tile_rec(L["steps"], x, L["frozen"], L["coefs"], norm_ord)
+                windows, live_bbox = self._live_plan(L["steps"], in_bboxes[i], out_bboxes[i])
+                x = self._run_tile_rec(L["steps"], x, L["frozen"], L["coefs"], norm_ord, windows)
                 if L["result"] is None:
                     oh, ow = (height * 8, width * 8) if self.is_decoder else (height // 8, width // 8)
                     L["result"] = torch.zeros((N, x.shape[1], oh, ow), device=d, dtype=torch.float32)
                 L["flags"].append(torch.isnan(x).all())
-                E.crop_store(x, in_bboxes[i], out_bboxes[i], L["result"], self.is_decoder)
+                E.crop_store(x, live_bbox, out_bboxes[i], L["result"], self.is_decoder)
                 L["mine"].append(i)
         if all(L["result"] is None for L in per):
             # interrupted before any tile finished: as the single-device path (and upstream, :644-650)
@@ -526,6 +597,7 @@ class VAEHook:
         interrupted = False
 
         nan_flags = []
+        live: Dict[int, tuple] = {}      # tile -> (windows of its upsample convs, the input bbox of what is left of it): live_windows
 
         def finish(i: int):
             nonlocal result
@@ -534,7 +606,7 @@ class VAEHook:
                 oh, ow = (height * 8, width * 8) if self.is_decoder else (height // 8, width // 8)
                 result = torch.zeros((N, x.shape[1], oh, ow), device=dev, dtype=torch.float32)
             nan_flags.append(torch.isnan(x).all())       # upstream tests every tile (:626); here ONE host read per decode, below
-            E.crop_store(x, in_bboxes[i], out_bboxes[i], result, self.is_decoder)
+            E.crop_store(x, live[i][1] if i in live else in_bboxes[i], out_bboxes[i], result, self.is_decoder)
             tiles[i] = None
 
         n_norm_total = sum(1 for s in steps if s.kind == "norm")
@@ -547,15 +619,18 @@ class VAEHook:
                 norm_ord = {i: k for k, i in enumerate(i for i, s in enumerate(steps) if s.kind == "norm")}
                 coefs = [E.gn_coeffs(mean, var, steps[i].norm[0], steps[i].norm[1], steps[i].channels, 32, 1e-6)
                          for i, (var, mean) in zip(norm_ord, frozen)]
+                for i in mine:
+                    live[i] = self._live_plan(steps, in_bboxes[i], out_bboxes[i])
             if use_rec and TILE_BATCH > 1:
                 # Tiles of one shape go through the sweep TOGETHER (stacked along the batch axis, TILE_BATCH at a time).  Upstream
                 # walks them one by one (:578-642); with frozen statistics they are independent, so the result is the same -- but
                 # a conv launch over one tile fills the 256 CUs in ceil(items / 256) rounds and the last round is mostly empty
                 # (256 -> 256 at 1112^2: 4 900 items = 19.1 rounds, 4 % idle; 512 -> 512 at 278^2: 2.5 rounds, 16 % idle).
                 # 288 GB of HBM hold several tiles' activations at once (3 tiles of 278^2: ~40 GB).
-                groups: Dict[Tuple[int, int], List[int]] = {}
+                # (stacked tiles share one set of launches, hence one set of live windows: same shape AND same valid rectangle)
+                groups: Dict[tuple, List[int]] = {}
                 for i in mine:
-                    groups.setdefault(tuple(tiles[i].x.shape[2:]), []).append(i)
+                    groups.setdefault(tuple(tiles[i].x.shape[2:]) + tuple(sorted(live[i][0].items())), []).append(i)
 
                 def run_chunk(chunk):
                     T = len(chunk)
@@ -565,7 +640,7 @@ class VAEHook:
                     if T > 1:
                         for i in chunk:
                             tiles[i].x = None          # the stacked copy is the live one
-                    yb = self._run_tile_rec(steps, xb, fz, cf, norm_ord)
+                    yb = self._run_tile_rec(steps, xb, fz, cf, norm_ord, live[chunk[0]][0])
                     for t, i in enumerate(chunk):
                         tiles[i].x = yb[t * N:(t + 1) * N]
                         finish(i)
@@ -574,7 +649,7 @@ class VAEHook:
                     ids = groups[shape_key]
                     # upstream sizes the TILE so that ONE tile's activations fit the card (:79-99); stacking is only taken when the
                     # stacked sweep fits what is free right now, and a sweep that still runs out of memory is repeated tile by tile
-                    tb = self._tile_batch_that_fits(N, shape_key, dev)
+                    tb = self._tile_batch_that_fits(N, shape_key[:2], dev)
                     c0 = 0
                     while c0 < len(ids):
                         if state.interrupted:
@@ -603,7 +678,7 @@ class VAEHook:
                     break
                 st, k = tiles[i], 0
                 if use_rec:
-                    st.x = self._run_tile_rec(steps, st.x, frozen, coefs, norm_ord)
+                    st.x = self._run_tile_rec(steps, st.x, frozen, coefs, norm_ord, live[i][0])
                     finish(i)
                     continue
                 while True:

@@ -162,3 +162,91 @@ def test_tiled_encode_record_path(plugin, cuda):
     hook = plugin.tilevae.VAEHook(enc, 64, is_decoder=False, fast_decoder=False, fast_encoder=True, color_fix=False)
     out = hook(x.to(cuda)).cpu()
     assert _rel(out, ref) < 2e-4
+
+
+# ---- live-window narrowing (mdtile_upconv2d_rec_window; scripts/tilevae.py: live_windows) ---------------------------------------------
+WINDOW_CASES = [  # B, cin, cout, Hin, Win, (y0, x0, h, w)
+    (1, 128, 128, 40, 70, (4, 4, 30, 60)),        # interior window: all four edges read the image's own neighbours
+    (1, 128, 128, 40, 70, (0, 0, 33, 41)),        # anchored top-left: two edges are the image's zero border
+    (2, 256, 128, 37, 50, (5, 9, 32, 41)),        # ends on the bottom / right edge of the image, batch 2, ragged input tiles
+    (1, 512, 512, 24, 40, (3, 6, 9, 31)),         # 4 cout blocks, window smaller than one block row
+    (1, 96, 128, 19, 66, (1, 1, 17, 64)),         # NK = 6
+    (1, 256, 256, 64, 64, (0, 0, 64, 64)),        # the whole image as a window == the plain call
+]
+
+
+@pytest.mark.parametrize("B,cin,cout,Hin,Win,win", WINDOW_CASES)
+def test_upconv_window_equals_the_same_pixels_of_the_whole_image_call(plugin, cuda, B, cin, cout, Hin, Win, win):
+    """Bit for bit: the arithmetic of an output pixel does not depend on where its block sits."""
+    E = plugin.engine
+    torch.manual_seed(cin + Hin)
+    conv = torch.nn.Conv2d(cin, cout, 3, 1, 1)
+    pc = E.PackedConv(conv.weight.detach().to(cuda), conv.bias.detach().to(cuda))
+    x = torch.randn(B, cin, Hin, Win).to(cuda)
+    coef = _coef(B, cout, 5).to(cuda)
+    xr = E.rec_from_f32(x)
+    y_full, r_full = pc.call_rec(xr, upsample2x=True, want_f32=True, want_rec=True, rec_coef=coef)
+    y0, x0, h, w = win
+    y_win, r_win = pc.call_rec(xr, upsample2x=True, want_f32=True, want_rec=True, rec_coef=coef, window=win)
+    assert y_win.shape == (B, cout, 2 * h, 2 * w) and r_win.shape == (B, cout, 2 * h, 2 * w)
+    assert torch.equal(y_win, y_full[:, :, 2 * y0:2 * (y0 + h), 2 * x0:2 * (x0 + w)])
+    assert torch.equal(r_win.to_f32(), r_full.to_f32()[:, :, 2 * y0:2 * (y0 + h), 2 * x0:2 * (x0 + w)])
+    # the record output is a well-formed image of its own: the same records as the whole-image call inside, a ZERO border around
+    # (the next conv's padding -- not the neighbours the whole image has there)
+    dw = r_win.data.view(B, 2, cout // 8, 2 * h + 2, 2 * w + 2, 4)
+    df = r_full.data.view(B, 2, cout // 8, 2 * Hin + 2, 2 * Win + 2, 4)
+    assert torch.equal(dw[:, :, :, 1:-1, 1:-1], df[:, :, :, 1 + 2 * y0:1 + 2 * (y0 + h), 1 + 2 * x0:1 + 2 * (x0 + w)])
+    assert not dw[:, :, :, 0].any() and not dw[:, :, :, -1].any() and not dw[:, :, :, :, 0].any() and not dw[:, :, :, :, -1].any()
+    # and against torch fp32
+    with torch.no_grad():
+        ref = conv.to(cuda)(F.interpolate(x, scale_factor=2.0, mode="nearest"))[:, :, 2 * y0:2 * (y0 + h), 2 * x0:2 * (x0 + w)]
+    assert _rel(y_win, ref) < 5e-5
+
+
+def test_upconv_window_rejects_a_window_outside_the_image(plugin, cuda):
+    E = plugin.engine
+    conv = torch.nn.Conv2d(128, 128, 3, 1, 1)
+    pc = E.PackedConv(conv.weight.detach().to(cuda), conv.bias.detach().to(cuda))
+    xr = E.rec_from_f32(torch.randn(1, 128, 16, 16, device=cuda))
+    for bad in ((0, 0, 17, 16), (-1, 0, 8, 8), (4, 10, 8, 8), (0, 0, 0, 4)):
+        with pytest.raises(E.MdtileError):
+            pc.call_rec(xr, upsample2x=True, window=bad)
+
+
+@pytest.mark.parametrize("hw,ts", [((64, 88), 32), ((40, 40), 64)])
+def test_fast_decode_with_live_windows_equals_the_whole_tile_sweep(plugin, cuda, hw, ts):
+    """Full-width SD decoder, fast mode: tiles narrowed where the resolution doubles (default) == whole padded tiles, BIT FOR BIT on the
+    assembled image (tiles of 54^2 / 54 x 50 latent px incl. image-edge tiles; one tile = no padding = nothing to shed); the narrowed
+    sweep issues smaller launches."""
+    tv = plugin.tilevae
+    dec = ld.make_decoder(5).to(cuda)
+    dec.original_forward = dec.forward
+    torch.manual_seed(hw[0])
+    z = torch.randn(1, 4, *hw).to(cuda)
+    outs, px = {}, {}
+    orig = plugin.engine.PackedConv.call_rec
+    old = tv.LIVE_WINDOW
+    try:
+        for live in (True, False):
+            tv.LIVE_WINDOW = live
+            count = [0, 0]
+
+            def counted(self, x, *a, **kw):
+                y, yr = orig(self, x, *a, **kw)
+                o = y if y is not None else yr
+                count[0] += o.shape[0] * o.shape[1] * o.shape[2] * o.shape[3]
+                count[1] += 1 if kw.get("window") else 0
+                return y, yr
+
+            plugin.engine.PackedConv.call_rec = counted
+            hook = tv.VAEHook(dec, ts, is_decoder=True, fast_decoder=True, fast_encoder=False, color_fix=False)
+            outs[live] = hook(z).cpu()
+            px[live] = tuple(count)
+    finally:
+        tv.LIVE_WINDOW = old
+        plugin.engine.PackedConv.call_rec = orig
+    assert torch.equal(outs[True], outs[False])
+    if ts < min(hw):
+        assert px[True][1] > 0 and px[False][1] == 0 and px[True][0] < 0.9 * px[False][0], px
+    else:
+        assert px[True] == px[False]

@@ -132,3 +132,67 @@ def test_sharded_decode_with_a_rank_that_owns_no_tile(fast):
         p.join(timeout=60)
     bad = [f"rank {r}: {msg}" for r, msg in results if msg != "ok"]
     assert not bad, "\n".join(bad)
+
+
+# ---- live-window narrowing of the fast-mode decoder tiles (scripts/tilevae.py: live_windows, _live_plan) -----------------------------
+def _rec_hook(net, ts, fast=True):
+    import torch_engine as te
+    hook = _hook(net, ts, True, fast)
+    hook.engine, hook._pack = te.TorchEngineRec(), te.TorchConvRec      # the record-path sweep (_run_tile_rec) on torch doubles
+    return hook
+
+
+def test_live_windows_of_the_sd_decoder_program():
+    """Grow = 1 / 3 / 7 latent px behind the 8x / 4x / 2x upsample convs (3 resblocks per level + conv_out), the 1x level whole; windows
+    nest, are clamped to the tile and are given in input px of each upsample conv relative to its already narrowed input plane."""
+    from oracle import ldm_decoder as ld
+    hook = _rec_hook(ld.make_decoder(0, small=True), 16)
+    pl = sys.modules[type(hook).__module__]
+    steps = hook.program()
+    ups = [i for i, s in enumerate(steps) if s.kind == "conv" and s.upsample]
+    assert len(ups) == 3
+    # interior tile: 11 latent px of padding on every side of a 16 x 24 valid rectangle
+    win, rect = pl.live_windows(steps, (38, 46), (11, 11, 27, 35))
+    assert rect == (10, 10, 28, 36)                                             # valid grown by 1
+    assert win[ups[0]] == (4, 4, 30, 38)                                        # 1x plane -> valid grown by 7, in 1x px
+    assert win[ups[1]] == (4 * 2, 4 * 2, 22 * 2, 30 * 2)                        # 2x plane (origin 4) -> valid grown by 3: offset 4 latent px
+    assert win[ups[2]] == (2 * 4, 2 * 4, 18 * 4, 26 * 4)                        # 4x plane (origin 8) -> valid grown by 1: offset 2 latent px
+    # tile in the top-left corner of the image: no padding there, nothing to shed on those sides
+    win, rect = pl.live_windows(steps, (27, 35), (0, 0, 16, 24))
+    assert rect == (0, 0, 17, 25)
+    assert win[ups[0]] == (0, 0, 23, 31) and win[ups[1]] == (0, 0, 19 * 2, 27 * 2) and win[ups[2]] == (0, 0, 17 * 4, 25 * 4)
+    # padding smaller than the reach of the convs: only the levels that can shed something get a window
+    win, rect = pl.live_windows(steps, (22, 22), (3, 3, 19, 19))
+    assert rect == (2, 2, 20, 20) and ups[0] not in win and ups[1] not in win and win[ups[2]] == (2 * 4, 2 * 4, 18 * 4, 18 * 4)
+    # the encoder has no upsample conv (and its attention comes last): nothing
+    ehook = _hook(ld.make_encoder(0, small=True), 64, False, True)
+    assert pl.live_windows(ehook.program(), (128, 128), (32, 32, 96, 96)) == ({}, (0, 0, 128, 128))
+
+
+@pytest.mark.parametrize("hw,ts", [((36, 44), 16), ((64, 40), 24)])
+def test_fast_decode_with_live_windows_matches_oracle_and_the_whole_tile_sweep(hw, ts):
+    """The record-path sweep on torch doubles: narrowed tiles == whole padded tiles (bit for bit: the same arithmetic per kept pixel)
+    == the oracle; and the narrowing does shed work."""
+    from oracle import ldm_decoder as ld, vae_oracle as vo
+    import torch_engine as te
+    torch.manual_seed(5)
+    z = torch.randn(1, 4, *hw)
+    with torch.no_grad():
+        ref = vo.tiled_forward(ld.make_decoder(0, small=True), z, ts, True)
+    outs, px = {}, {}
+    for live in (True, False):
+        hook = _rec_hook(ld.make_decoder(0, small=True), ts)
+        pl = sys.modules[type(hook).__module__]
+        old = pl.LIVE_WINDOW
+        pl.LIVE_WINDOW = live
+        te.TorchConvRec.px_computed = te.TorchConvRec.window_calls = 0
+        try:
+            with torch.no_grad():
+                outs[live] = hook(z)
+        finally:
+            pl.LIVE_WINDOW = old
+        px[live] = te.TorchConvRec.px_computed
+        assert (te.TorchConvRec.window_calls > 0) == live
+    assert torch.equal(outs[True], outs[False])
+    assert (outs[True] - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    assert px[True] < 0.9 * px[False], f"narrowing shed only {1 - px[True] / px[False]:.1%} of the conv outputs"

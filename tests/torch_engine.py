@@ -131,3 +131,50 @@ class TorchSeqParOps:
 
     def tanh(self, x):
         return torch.tanh(x)
+
+
+# ---- record-path doubles: the fast-mode sweep of scripts/tilevae.py (_run_tile_rec) with the hand-over between the 3x3 convs emulated
+# in fp32 torch, so that the host logic of that sweep -- which producer applies which norm, the live-window narrowing of the tiles
+# (live_windows), stacking by shape -- is checked against the oracle on CPU.
+class TorchRec:
+    """Stand-in for mdtile.RecImage: the (already activated) fp32 tensor itself."""
+
+    def __init__(self, t):
+        self.t = t
+        self.shape = tuple(t.shape)
+
+
+class TorchConvRec(TorchConv):
+    px_computed = 0      # output pixels x couts of every call_rec (what a narrowed sweep saves)
+    window_calls = 0
+
+    def takes_rec(self, upsample2x=False):
+        return self.ksize == 3 and not self.down and self.cin % 32 == 0 and self.cout % 32 == 0
+
+    def call_rec(self, xrec, residual=None, upsample2x=False, want_f32=True, want_rec=False, rec_coef=None, window=None):
+        x = xrec.t
+        if window is not None:
+            # mdtile_upconv2d_rec_window: the conv of a window of the input whose edges inside the image see the true neighbours ==
+            # the same pixels of the whole-image result
+            assert upsample2x and residual is None
+            y0, x0, h, w = window
+            assert 0 <= y0 and 0 <= x0 and y0 + h <= x.shape[2] and x0 + w <= x.shape[3]
+            full = self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+            y = full[:, :, 2 * y0:2 * (y0 + h), 2 * x0:2 * (x0 + w)].contiguous()
+            TorchConvRec.window_calls += 1
+        else:
+            if upsample2x:
+                x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+            y = self.conv(x)
+        TorchConvRec.px_computed += y.shape[0] * y.shape[1] * y.shape[2] * y.shape[3]
+        if residual is not None:
+            y = y + residual
+        yr = None
+        if want_rec:
+            yr = TorchRec(F.silu(y * rec_coef[:, 0, :, None, None] + rec_coef[:, 1, :, None, None]) if rec_coef is not None else y)
+        return (y if want_f32 else None), yr
+
+
+class TorchEngineRec(TorchEngine):
+    def rec_from_f32(self, x, coef=None):
+        return TorchRec(F.silu(x * coef[:, 0, :, None, None] + coef[:, 1, :, None, None]) if coef is not None else x)
