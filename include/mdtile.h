@@ -298,11 +298,12 @@ int mdtile_conv2d_rec(const void* d_x_rec, const float* d_w_packed, const float*
  * whole padded tile and crop_valid_region (tilevae.py:248-259, applied at :630-632) throws the padding away at the end; a pixel the remaining
  * 3x3 convs cannot carry into the valid region need not be computed at all.  The narrowing happens where the resolution doubles:
  *   mdtile_upconv2d_rec_window : the fused nearest-2x upsample conv (ldm Upsample, tilevae.py:139-153) of the window
- *                                [y0 : y0 + h, x0 : x0 + w] of the record image of [B, cin, Hin, Win]; outputs are [B, cout, 2h, 2w] (fp32 d_y
+ *                                [y0[b] : y0[b] + h, x0[b] : x0[b] + w] of image b of the record image of [B, cin, Hin, Win] (y0, x0: HOST arrays
+ *                                of B ints -- stacked tiles of one shape keep their own origins; beyond 8 images the origins must repeat every 8); outputs are [B, cout, 2h, 2w] (fp32 d_y
  *                                and / or record image d_y_rec with d_y_coef as in mdtile_conv2d_rec).  Window edges inside the image read the
  *                                image's real neighbours, so the outputs equal the same pixels of the whole-image call bit for bit. */
 int mdtile_upconv2d_rec_window(const void* d_x_rec, const float* d_w_packed, const float* d_bias, float* d_y, void* d_y_rec,
-                               const float* d_y_coef, int B, int cin, int cout, int Hin, int Win, int y0, int x0, int h, int w,
+                               const float* d_y_coef, int B, int cin, int cout, int Hin, int Win, const int* y0, const int* x0, int h, int w,
                                mdtile_stream_t stream);
 
 /* Row-band pieces of get_var_mean (tilevae.py:207-215) for an activation that is split by rows across GPUs (sequence-parallel

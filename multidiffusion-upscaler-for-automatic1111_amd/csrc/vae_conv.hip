@@ -243,7 +243,7 @@ size_t rec_image_bytes(int B, int C, int H, int W);
 int rec_from_f32_launch(const float* d_x, const float* d_coef, void* d_rec, int B, int C, int H, int W, hipStream_t s);
 int rec_to_f32_launch(const void* d_rec, float* d_x, int B, int C, int H, int W, hipStream_t s);
 int conv_rec_launch(const void* d_xrec, const void* d_w_rec, const float* d_bias, const float* d_res, float* d_y32, void* d_yrec,
-                    const float* d_ycoef, int B, int cin, int cout, int H, int W, int up, hipStream_t s, const int* win4 = nullptr);
+                    const float* d_ycoef, int B, int cin, int cout, int H, int W, int up, hipStream_t s, const int* win = nullptr);
 // vae_conv1x1_bf16x3.hip
 bool conv1x1_bf16x3_eligible(int cout, int cin);
 size_t conv1x1_bf16x3_packed_floats(int cout, int cin);
@@ -372,17 +372,27 @@ extern "C" int mdtile_conv2d_rec(const void* d_x_rec, const float* d_w_packed, c
 
 // Nearest-2x + 3x3 conv of a WINDOW of the input record image (live-window narrowing of the decoder tiles, see include/mdtile.h)
 extern "C" int mdtile_upconv2d_rec_window(const void* d_x_rec, const float* d_w_packed, const float* d_bias, float* d_y, void* d_y_rec,
-                                          const float* d_y_coef, int B, int cin, int cout, int Hin, int Win, int y0, int x0, int h, int w,
-                                          mdtile_stream_t stream) {
-    MDT_CHECK_ARG(d_x_rec && d_w_packed && (d_y || d_y_rec), "mdtile_upconv2d_rec_window: null argument (one of d_y / d_y_rec is required)");
+                                          const float* d_y_coef, int B, int cin, int cout, int Hin, int Win, const int* y0, const int* x0,
+                                          int h, int w, mdtile_stream_t stream) {
+    MDT_CHECK_ARG(d_x_rec && d_w_packed && (d_y || d_y_rec) && y0 && x0, "mdtile_upconv2d_rec_window: null argument (one of d_y / d_y_rec is required)");
     MDT_CHECK_ARG(mdtile_conv2d_rec_supported(cout, cin, 3, 0) && cout % 128 == 0, "mdtile_upconv2d_rec_window: no record kernel for cout=%d cin=%d", cout, cin);
-    MDT_CHECK_ARG(h >= 1 && w >= 1 && y0 >= 0 && x0 >= 0 && y0 + h <= Hin && x0 + w <= Win,
-                  "mdtile_upconv2d_rec_window: window y0=%d x0=%d h=%d w=%d leaves the %dx%d input", y0, x0, h, w, Hin, Win);
+    MDT_CHECK_ARG(B >= 1, "mdtile_upconv2d_rec_window: B=%d", B);
+    int win[2 + 2 * 8] = {Hin, Win};
+    for (int b = 0; b < B; ++b) {
+        MDT_CHECK_ARG(h >= 1 && w >= 1 && y0[b] >= 0 && x0[b] >= 0 && y0[b] + h <= Hin && x0[b] + w <= Win,
+                      "mdtile_upconv2d_rec_window: window y0=%d x0=%d h=%d w=%d of image %d leaves the %dx%d input", y0[b], x0[b], h, w, b, Hin, Win);
+        // the kernel keeps 8 origins (image b uses slot b & 7): more images only when they repeat with that period
+        MDT_CHECK_ARG(b < 8 || (y0[b] == y0[b & 7] && x0[b] == x0[b & 7]),
+                      "mdtile_upconv2d_rec_window: more than 8 images need window origins that repeat every 8 images (image %d)", b);
+    }
+    for (int b = 0; b < 8; ++b) {
+        win[2 + 2 * b] = y0[b % B];
+        win[3 + 2 * b] = x0[b % B];
+    }
     MDT_CHECK_ARG(rec_image_ok(B, cin, Hin, Win) && rec_image_ok(B, cout, 2 * h, 2 * w),
                   "mdtile_upconv2d_rec_window: unsupported shape B=%d cin=%d cout=%d Hin=%d Win=%d", B, cin, cout, Hin, Win);
-    const int win4[4] = {Hin, Win, y0, x0};
     return conv_rec_launch(d_x_rec, d_w_packed + f32_packed_floats(cout, cin, 3), d_bias, nullptr, d_y, d_y_rec, d_y_coef, B, cin, cout,
-                           2 * h, 2 * w, 1, as_stream(stream), win4);
+                           2 * h, 2 * w, 1, as_stream(stream), win);
 }
 
 // ldm Downsample: y = conv3x3_stride2(pad(x, right 1, bottom 1)); output (Hin - 2) / 2 + 1 rows (likewise columns).

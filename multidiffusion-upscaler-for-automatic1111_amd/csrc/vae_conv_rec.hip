@@ -42,6 +42,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+constexpr int REC_WIN_MAXB = 8;   // images per launch that may carry a window origin of their own (stacked tiles of one shape)
+
 struct ConvRParams {
     const u32x4* x;      // input record image [B][2][Cin/8][Hin+2][Win+2]
     const u32x4* w;      // packed weights (vae_conv_bf16x3.hip: k_conv_pack_bf16x3 / k_upconv_pack_bf16x3, permuted K order)
@@ -52,7 +54,8 @@ struct ConvRParams {
     const float* coef;   // activation of the record output: [B][2][Cout] = (a, s), yrec = split(silu(a y + s)); null = split(y)
     int B, Cin, Cout, H, W;   // H, W: OUTPUT size
     int Hin, Win;             // input size (= H, W; half of it for the sub-pixel upsample kernel)
-    int HinF, WinF, iy0, ix0; // sub-pixel upsample kernel: the input is the window [iy0 : iy0 + Hin, ix0 : ix0 + Win] of a record image of HinF x WinF px
+    int HinF, WinF;           // sub-pixel upsample kernel: image b's input is the window [iy0[b] : iy0[b] + Hin, ix0[b] : ix0[b] + Win] of a
+    int iy0[REC_WIN_MAXB], ix0[REC_WIN_MAXB];   // record image of HinF x WinF px (whole image: HinF = Hin, WinF = Win, all origins 0)
     int ptiles, PX, NCB, NK;  // pixel tiles, tiles per row, cout blocks, 16-channel K-steps
 };
 
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(512, 2) void k_upconv_rec(const ConvRParams P) {
             if (s >= IS::HALF) s = IS::HALF - 1;
             const int g = s / (ROWS * COLS), p = s - g * (ROWS * COLS);
             const int r = p / COLS, c = p - r * COLS;
-            int pr = P.iy0 + it.y0 + r, pc = P.ix0 + it.x0 + c;     // inside the window's own border: the image's real neighbours
+            int pr = P.iy0[it.b & (REC_WIN_MAXB - 1)] + it.y0 + r, pc = P.ix0[it.b & (REC_WIN_MAXB - 1)] + it.x0 + c;     // inside the window's own border: the image's real neighbours
             pr = pr < Hp ? pr : Hp - 1;
             pc = pc < Wp ? pc : Wp - 1;
             ioff[i] = (unsigned)(((size_t)g * plane + (size_t)pr * Wp + pc) * 16);
@@ -778,17 +781,20 @@ int rec_to_f32_launch(const void* d_rec, float* d_x, int B, int C, int H, int W,
     return MDTILE_OK;
 }
 
-// win4 (sub-pixel upsample kernel only, else null): {HinF, WinF, iy0, ix0} -- d_xrec is the record image of [B, cin, HinF, WinF] and the conv
-// reads its window [iy0 : iy0 + H/2, ix0 : ix0 + W/2]
+// win (sub-pixel upsample kernel only, else null): {HinF, WinF, y0[0], x0[0], ..., y0[7], x0[7]} -- d_xrec is the record image of
+// [B, cin, HinF, WinF] and image b's conv reads its window [y0[b & 7] : .. + H/2, x0[b & 7] : .. + W/2]  (all 8 slots filled)
 int conv_rec_launch(const void* d_xrec, const void* d_w_rec, const float* d_bias, const float* d_res, float* d_y32, void* d_yrec,
-                    const float* d_ycoef, int B, int cin, int cout, int H, int W, int up, hipStream_t s, const int* win4) {
+                    const float* d_ycoef, int B, int cin, int cout, int H, int W, int up, hipStream_t s, const int* win) {
     ConvRParams P;
     P.x = (const u32x4*)d_xrec; P.w = (const u32x4*)d_w_rec; P.bias = d_bias; P.res = d_res; P.y32 = d_y32;
     P.yrec = (u32x4*)d_yrec; P.coef = d_ycoef;
     P.B = B; P.Cin = cin; P.Cout = cout; P.H = H; P.W = W;
     P.Hin = up ? H / 2 : H; P.Win = up ? W / 2 : W;
-    P.HinF = win4 ? win4[0] : P.Hin; P.WinF = win4 ? win4[1] : P.Win;
-    P.iy0 = win4 ? win4[2] : 0; P.ix0 = win4 ? win4[3] : 0;
+    P.HinF = win ? win[0] : P.Hin; P.WinF = win ? win[1] : P.Win;
+    for (int b = 0; b < REC_WIN_MAXB; ++b) {       // (image b reads slot b & 7; the caller fills all 8)
+        P.iy0[b] = win ? win[2 + 2 * b] : 0;
+        P.ix0[b] = win ? win[3 + 2 * b] : 0;
+    }
     P.NCB = cout % 128 == 0 ? cout / 128 : 1;
     P.NK = cin / 16;
     if (up) {

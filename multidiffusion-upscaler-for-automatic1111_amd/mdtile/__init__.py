@@ -124,7 +124,8 @@ _SIGNATURES = {
     "mdtile_conv2d_rec_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "mdtile_conv2d_rec": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                   c_int, c_int, c_void_p]),
-    "mdtile_upconv2d_rec_window": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
+    "mdtile_upconv2d_rec_window": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_int, c_int,
+                                                                                                                  c_void_p]),
     "mdtile_vae_attn_ws_size": (c_size_t, [c_int, c_int, c_int]),
     "mdtile_vae_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p]),
     "mdtile_crop_store": (c_int, [c_void_p, c_int, c_int, c_int, c_int, _IP, _IP, c_int, c_void_p, c_int, c_int, c_void_p]),
@@ -729,20 +730,24 @@ class PackedConv:
                  want_rec: bool = False, rec_coef: Optional[torch.Tensor] = None, window: Optional[Tuple[int, int, int, int]] = None):
         """y = conv(x_rec) + bias (+ residual) -> (fp32 NCHW or None, RecImage or None).  The record output is
         split(silu(a y + s)) with rec_coef = gn_coeffs(...) of the NEXT norm, or split(y) when rec_coef is None.
-        window = (y0, x0, h, w) in INPUT pixels (upsample2x only): the conv of that window of x, outputs [B, cout, 2h, 2w]
-        (mdtile_upconv2d_rec_window: live-window narrowing of a decoder tile)."""
+        window = (y0, x0, h, w) in INPUT pixels (upsample2x only; y0, x0: ints, or one int per image): the conv of that window of x,
+        outputs [B, cout, 2h, 2w] (mdtile_upconv2d_rec_window: live-window narrowing of a decoder tile)."""
         B, cin, H, W = x.shape
         assert cin == self.cin and (want_f32 or want_rec)
         if window is not None:
             assert upsample2x and residual is None, "a window is taken by the upsample conv only"
-            y0, x0, h, w = (int(v) for v in window)
+            y0, x0, h, w = window
+            y0 = [int(y0)] * B if isinstance(y0, int) else [int(v) for v in y0]       # one origin for every image, or one per image
+            x0 = [int(x0)] * B if isinstance(x0, int) else [int(v) for v in x0]
+            assert len(y0) == len(x0) == B, f"{B} images but {len(y0)} / {len(x0)} window origins"
+            h, w = int(h), int(w)
             y = torch.empty((B, self.cout, 2 * h, 2 * w), dtype=torch.float32, device=x.data.device) if want_f32 else None
             yr = RecImage((B, self.cout, 2 * h, 2 * w), x.data.device) if want_rec else None
             if rec_coef is not None:
                 _dev_tensor(rec_coef, "rec_coef", torch.float32)
                 assert want_rec and tuple(rec_coef.shape) == (B, 2, self.cout)
             _check(lib().mdtile_upconv2d_rec_window(_p(x.data), _p(self.packed), _p(self.bias_rec), _p(y), None if yr is None else _p(yr.data),
-                                                    _p(rec_coef), B, self.cin, self.cout, H, W, y0, x0, h, w, _stream()),
+                                                    _p(rec_coef), B, self.cin, self.cout, H, W, (c_int * B)(*y0), (c_int * B)(*x0), h, w, _stream()),
                    "mdtile_upconv2d_rec_window")
             return y, yr
         if upsample2x:

@@ -185,10 +185,12 @@ def live_windows(steps: List["Step"], tile_hw: Tuple[int, int], valid: Tuple[int
     cheapest, at the upsample convs: walking the program backwards, `need` counts the 3x3 convs behind a point in pixels of that
     level; at the upsample conv that opens a level of `scale` px per latent px the plane becomes `valid` grown by
     ceil(need / scale) latent px (whole latent px: the tile's own crop and store stay in latent units), clamped to the tile, and
-    the level below has to provide that window halved plus the conv's own 1 px halo (read from the un-narrowed input image, so
-    it holds the true neighbours).  A narrowed plane is a zero-padded image of its own: its errors creep inwards one pixel per
-    conv and stop exactly at the valid region.  The walk ends at the attention (it needs every token of the tile).
-    SD decoder (3 resblocks per level, conv_out): grow = 1, 3, 7 latent px for the 8x, 4x, 2x levels; the 1x level stays whole.
+    the level below has to provide ceil((need + 1) / 2) px: an output pixel d px outside the valid region reads the nearest-2x
+    image d - 1 .. d + 1 px outside, i.e. input pixels up to ceil((d + 1) / 2) px outside (the window's own outermost inputs come
+    from the un-narrowed input image, so they are its true neighbours).  A narrowed plane is a zero-padded image of its own: its
+    errors creep inwards one pixel per conv and stop at the valid region.  The walk ends at the attention (it needs every token).
+    SD decoder (3 resblocks per level, conv_out): need = 7, 10, 12 px -> grow = 1, 3, 6 latent px for the 8x, 4x, 2x levels; the 1x
+    level would need 13 of its 11 px of padding and stays whole.  (tests/test_vae_host_logic.py: exact and tight in float64.)
 
     Returns ({index of the upsample step: (y0, x0, h, w) window of ITS input plane, in input px}, final rect in latent px relative to
     the tile (y0, x0, y1, x1)) -- ({}, whole tile) when nothing can be shed."""
@@ -206,10 +208,9 @@ def live_windows(steps: List["Step"], tile_hw: Tuple[int, int], valid: Tuple[int
             continue                       # frozen norm, SiLU, residual bookkeeping (+ 1x1 nin_shortcut), tanh: pointwise
         ks = int(getattr(s.conv, "ksize", 3))
         if s.upsample:
-            m = -(-need // scale)          # whole latent px
-            grow[i] = m
+            grow[i] = -(-need // scale)    # whole latent px
             scale //= 2
-            need = m * scale + (ks // 2)
+            need = (need + ks // 2 + 1) // 2
         else:
             need += ks // 2
     vy0, vx0, vy1, vx1 = valid
@@ -627,10 +628,10 @@ class VAEHook:
                 # a conv launch over one tile fills the 256 CUs in ceil(items / 256) rounds and the last round is mostly empty
                 # (256 -> 256 at 1112^2: 4 900 items = 19.1 rounds, 4 % idle; 512 -> 512 at 278^2: 2.5 rounds, 16 % idle).
                 # 288 GB of HBM hold several tiles' activations at once (3 tiles of 278^2: ~40 GB).
-                # (stacked tiles share one set of launches, hence one set of live windows: same shape AND same valid rectangle)
+                # (stacked tiles share their launches: same shape AND live windows of the same SIZE -- each keeps its own window origin)
                 groups: Dict[tuple, List[int]] = {}
                 for i in mine:
-                    groups.setdefault(tuple(tiles[i].x.shape[2:]) + tuple(sorted(live[i][0].items())), []).append(i)
+                    groups.setdefault(tuple(tiles[i].x.shape[2:]) + tuple((k, w[2], w[3]) for k, w in sorted(live[i][0].items())), []).append(i)
 
                 def run_chunk(chunk):
                     T = len(chunk)
@@ -640,7 +641,9 @@ class VAEHook:
                     if T > 1:
                         for i in chunk:
                             tiles[i].x = None          # the stacked copy is the live one
-                    yb = self._run_tile_rec(steps, xb, fz, cf, norm_ord, live[chunk[0]][0])
+                    wins = {k: ([live[i][0][k][0] for i in chunk for _ in range(N)], [live[i][0][k][1] for i in chunk for _ in range(N)], w[2], w[3])
+                            for k, w in live[chunk[0]][0].items()}
+                    yb = self._run_tile_rec(steps, xb, fz, cf, norm_ord, wins)
                     for t, i in enumerate(chunk):
                         tiles[i].x = yb[t * N:(t + 1) * N]
                         finish(i)
@@ -650,6 +653,8 @@ class VAEHook:
                     # upstream sizes the TILE so that ONE tile's activations fit the card (:79-99); stacking is only taken when the
                     # stacked sweep fits what is free right now, and a sweep that still runs out of memory is repeated tile by tile
                     tb = self._tile_batch_that_fits(N, shape_key[:2], dev)
+                    if len(shape_key) > 2 and tb * N > 8:
+                        tb = max(1, 8 // N)        # mdtile_upconv2d_rec_window keeps 8 window origins per launch
                     c0 = 0
                     while c0 < len(ids):
                         if state.interrupted:

@@ -203,6 +203,33 @@ def test_upconv_window_equals_the_same_pixels_of_the_whole_image_call(plugin, cu
     assert _rel(y_win, ref) < 5e-5
 
 
+def test_upconv_window_origin_per_image(plugin, cuda):
+    """Stacked tiles of one shape keep their own window origin (left- and right-edge tiles of an image): image b of the launch reads
+    the window at (y0[b], x0[b]); 12 images with origins that repeat every 8 are taken too, other patterns beyond 8 are refused."""
+    E = plugin.engine
+    torch.manual_seed(4)
+    conv = torch.nn.Conv2d(128, 128, 3, 1, 1)
+    pc = E.PackedConv(conv.weight.detach().to(cuda), conv.bias.detach().to(cuda))
+    B, Hin, Win, h, w = 5, 30, 44, 21, 35
+    x = torch.randn(B, 128, Hin, Win).to(cuda)
+    xr = E.rec_from_f32(x)
+    y_full, _ = pc.call_rec(xr, upsample2x=True)
+    y0s, x0s = [0, 9, 4, 0, 7], [9, 0, 3, 0, 9]
+    y_win, r_win = pc.call_rec(xr, upsample2x=True, want_rec=True, window=(y0s, x0s, h, w))
+    for b in range(B):
+        assert torch.equal(y_win[b], y_full[b, :, 2 * y0s[b]:2 * (y0s[b] + h), 2 * x0s[b]:2 * (x0s[b] + w)]), f"image {b}"
+    assert torch.equal(r_win.to_f32(), y_win) or _rel(r_win.to_f32(), y_win) < 2.0 ** -15
+    x12 = torch.randn(12, 128, 12, 40).to(cuda)
+    xr12 = E.rec_from_f32(x12)
+    f12, _ = pc.call_rec(xr12, upsample2x=True)
+    o = [0, 1, 2, 3, 4, 3, 2, 1]
+    w12, _ = pc.call_rec(xr12, upsample2x=True, window=([o[b & 7] for b in range(12)], [2 * o[b & 7] for b in range(12)], 8, 32))
+    for b in range(12):
+        assert torch.equal(w12[b], f12[b, :, 2 * o[b & 7]:2 * o[b & 7] + 16, 4 * o[b & 7]:4 * o[b & 7] + 64])
+    with pytest.raises(E.MdtileError):
+        pc.call_rec(xr12, upsample2x=True, window=([b % 3 for b in range(12)], [0] * 12, 8, 32))
+
+
 def test_upconv_window_rejects_a_window_outside_the_image(plugin, cuda):
     E = plugin.engine
     conv = torch.nn.Conv2d(128, 128, 3, 1, 1)

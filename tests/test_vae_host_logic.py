@@ -143,7 +143,7 @@ def _rec_hook(net, ts, fast=True):
 
 
 def test_live_windows_of_the_sd_decoder_program():
-    """Grow = 1 / 3 / 7 latent px behind the 8x / 4x / 2x upsample convs (3 resblocks per level + conv_out), the 1x level whole; windows
+    """Grow = 1 / 3 / 6 latent px behind the 8x / 4x / 2x upsample convs (3 resblocks per level + conv_out), the 1x level whole; windows
     nest, are clamped to the tile and are given in input px of each upsample conv relative to its already narrowed input plane."""
     from oracle import ldm_decoder as ld
     hook = _rec_hook(ld.make_decoder(0, small=True), 16)
@@ -154,13 +154,13 @@ def test_live_windows_of_the_sd_decoder_program():
     # interior tile: 11 latent px of padding on every side of a 16 x 24 valid rectangle
     win, rect = pl.live_windows(steps, (38, 46), (11, 11, 27, 35))
     assert rect == (10, 10, 28, 36)                                             # valid grown by 1
-    assert win[ups[0]] == (4, 4, 30, 38)                                        # 1x plane -> valid grown by 7, in 1x px
-    assert win[ups[1]] == (4 * 2, 4 * 2, 22 * 2, 30 * 2)                        # 2x plane (origin 4) -> valid grown by 3: offset 4 latent px
+    assert win[ups[0]] == (5, 5, 28, 36)                                        # 1x plane -> valid grown by 6, in 1x px
+    assert win[ups[1]] == (3 * 2, 3 * 2, 22 * 2, 30 * 2)                        # 2x plane (origin 5) -> valid grown by 3: offset 3 latent px
     assert win[ups[2]] == (2 * 4, 2 * 4, 18 * 4, 26 * 4)                        # 4x plane (origin 8) -> valid grown by 1: offset 2 latent px
     # tile in the top-left corner of the image: no padding there, nothing to shed on those sides
     win, rect = pl.live_windows(steps, (27, 35), (0, 0, 16, 24))
     assert rect == (0, 0, 17, 25)
-    assert win[ups[0]] == (0, 0, 23, 31) and win[ups[1]] == (0, 0, 19 * 2, 27 * 2) and win[ups[2]] == (0, 0, 17 * 4, 25 * 4)
+    assert win[ups[0]] == (0, 0, 22, 30) and win[ups[1]] == (0, 0, 19 * 2, 27 * 2) and win[ups[2]] == (0, 0, 17 * 4, 25 * 4)
     # padding smaller than the reach of the convs: only the levels that can shed something get a window
     win, rect = pl.live_windows(steps, (22, 22), (3, 3, 19, 19))
     assert rect == (2, 2, 20, 20) and ups[0] not in win and ups[1] not in win and win[ups[2]] == (2 * 4, 2 * 4, 18 * 4, 18 * 4)
@@ -169,23 +169,22 @@ def test_live_windows_of_the_sd_decoder_program():
     assert pl.live_windows(ehook.program(), (128, 128), (32, 32, 96, 96)) == ({}, (0, 0, 128, 128))
 
 
-@pytest.mark.parametrize("hw,ts", [((36, 44), 16), ((64, 40), 24)])
-def test_fast_decode_with_live_windows_matches_oracle_and_the_whole_tile_sweep(hw, ts):
-    """The record-path sweep on torch doubles: narrowed tiles == whole padded tiles (bit for bit: the same arithmetic per kept pixel)
-    == the oracle; and the narrowing does shed work."""
+@pytest.mark.parametrize("hw,ts,stacked_origins", [((36, 44), 16, False), ((70, 40), 16, True), ((64, 40), 24, False)])
+def test_fast_decode_with_live_windows_matches_oracle_and_the_whole_tile_sweep(hw, ts, stacked_origins):
+    """The record-path sweep on torch doubles: narrowed tiles == whole padded tiles == the oracle; and the narrowing does shed work."""
     from oracle import ldm_decoder as ld, vae_oracle as vo
     import torch_engine as te
     torch.manual_seed(5)
     z = torch.randn(1, 4, *hw)
     with torch.no_grad():
         ref = vo.tiled_forward(ld.make_decoder(0, small=True), z, ts, True)
-    outs, px = {}, {}
+    outs, px, mixed = {}, {}, {}
     for live in (True, False):
         hook = _rec_hook(ld.make_decoder(0, small=True), ts)
         pl = sys.modules[type(hook).__module__]
         old = pl.LIVE_WINDOW
         pl.LIVE_WINDOW = live
-        te.TorchConvRec.px_computed = te.TorchConvRec.window_calls = 0
+        te.TorchConvRec.px_computed = te.TorchConvRec.window_calls = te.TorchConvRec.mixed_origin_calls = 0
         try:
             with torch.no_grad():
                 outs[live] = hook(z)
@@ -193,6 +192,53 @@ def test_fast_decode_with_live_windows_matches_oracle_and_the_whole_tile_sweep(h
             pl.LIVE_WINDOW = old
         px[live] = te.TorchConvRec.px_computed
         assert (te.TorchConvRec.window_calls > 0) == live
-    assert torch.equal(outs[True], outs[False])
+        mixed[live] = te.TorchConvRec.mixed_origin_calls
+    # (torch's CPU conv picks its blocking by plane size, so the doubles agree to rounding only; the engine's kernels are bit-identical:
+    # tests/test_gpu_rec.py::test_fast_decode_with_live_windows_equals_the_whole_tile_sweep)
+    assert (outs[True] - outs[False]).abs().max().item() <= 1e-5 * ref.abs().max().item()      # (exactness: the float64 test below)
     assert (outs[True] - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
     assert px[True] < 0.9 * px[False], f"narrowing shed only {1 - px[True] / px[False]:.1%} of the conv outputs"
+    # (70, 40) at tile 16: the first and the last tile of a column have one shape and windows of one size at different origins
+    assert (mixed[True] > 0) == stacked_origins, "stacked sweep of tiles with different window origins (first / last tile of a column)"
+
+
+def test_live_windows_are_exact_and_tight_in_float64():
+    """One tile through the record sweep in float64 (rounding out of the picture): inside the valid rectangle the narrowed sweep equals
+    the whole-tile sweep to float64 rounding, and windows one latent pixel smaller do NOT (the bound is the reach of the convs, not slack)."""
+    from oracle import ldm_decoder as ld
+    hook = _rec_hook(ld.make_decoder(3, small=True).double(), 16)
+    pl = sys.modules[type(hook).__module__]
+    steps = hook.program()
+    norm_idx = [i for i, s in enumerate(steps) if s.kind == "norm"]
+    norm_ord = {i: k for k, i in enumerate(norm_idx)}
+    g = torch.Generator().manual_seed(8)
+    frozen = [(torch.rand(32, generator=g, dtype=torch.float64) + 0.5, torch.randn(32, generator=g, dtype=torch.float64) * 0.1) for _ in norm_idx]
+    E = hook.engine
+    coefs = [E.gn_coeffs(m, v, steps[i].norm[0], steps[i].norm[1], steps[i].channels, 32, 1e-6) for i, (v, m) in zip(norm_idx, frozen)]
+    th, tw, valid = 38, 40, (11, 11, 27, 29)
+    x = torch.randn(1, 4, th, tw, generator=g, dtype=torch.float64)
+    with torch.no_grad():
+        whole = hook._run_tile_rec(steps, x, frozen, coefs, norm_ord, None)
+        windows, rect = pl.live_windows(steps, (th, tw), valid)
+        narrowed = hook._run_tile_rec(steps, x, frozen, coefs, norm_ord, windows)
+    assert len(windows) == 3 and narrowed.shape[2:] == ((rect[2] - rect[0]) * 8, (rect[3] - rect[1]) * 8)
+
+    def valid_of(t, r):
+        return t[:, :, (valid[0] - r[0]) * 8:(valid[2] - r[0]) * 8, (valid[1] - r[1]) * 8:(valid[3] - r[1]) * 8]
+
+    ref = valid_of(whole, (0, 0))
+    exact = (valid_of(narrowed, rect) - ref).abs().max().item() / ref.abs().max().item()
+    assert exact <= 1e-14, exact                     # rounding of float64 (the doubles' conv blocks by plane size)
+    # one latent pixel less at the 2x level (grow 5 = 10 px where 12 are needed): the convs reach the valid rectangle from outside the window
+    ups = sorted(windows)
+    y0, x0, h, w = windows[ups[0]]
+    tight = dict(windows)
+    tight[ups[0]] = (y0 + 1, x0 + 1, h - 2, w - 2)
+    y0, x0, h, w = windows[ups[1]]
+    tight[ups[1]] = (y0 - 2, x0 - 2, h, w)          # same absolute rectangle at the 4x level (its origin is relative to the 2x window)
+    with torch.no_grad():
+        short = hook._run_tile_rec(steps, x, frozen, coefs, norm_ord, tight)
+    assert short.shape == narrowed.shape
+    off = (valid_of(short, rect) - ref).abs().max().item() / ref.abs().max().item()
+    print(f"narrowed vs whole tile {exact:.1e}; windows one latent px short {off:.1e}")
+    assert off > 1e3 * max(exact, 1e-16), (exact, off)      # small (12 random convs damp it) but four orders above rounding

@@ -147,6 +147,7 @@ class TorchRec:
 class TorchConvRec(TorchConv):
     px_computed = 0      # output pixels x couts of every call_rec (what a narrowed sweep saves)
     window_calls = 0
+    mixed_origin_calls = 0     # window calls whose images (stacked tiles) have different origins
 
     def takes_rec(self, upsample2x=False):
         return self.ksize == 3 and not self.down and self.cin % 32 == 0 and self.cout % 32 == 0
@@ -158,10 +159,15 @@ class TorchConvRec(TorchConv):
             # the same pixels of the whole-image result
             assert upsample2x and residual is None
             y0, x0, h, w = window
-            assert 0 <= y0 and 0 <= x0 and y0 + h <= x.shape[2] and x0 + w <= x.shape[3]
+            B = x.shape[0]
+            y0 = [y0] * B if isinstance(y0, int) else list(y0)       # one origin for all images, or one per image (stacked tiles)
+            x0 = [x0] * B if isinstance(x0, int) else list(x0)
+            assert len(y0) == len(x0) == B and (B <= 8 or all(y0[b] == y0[b & 7] and x0[b] == x0[b & 7] for b in range(B)))
+            assert all(0 <= a and 0 <= c and a + h <= x.shape[2] and c + w <= x.shape[3] for a, c in zip(y0, x0))
             full = self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
-            y = full[:, :, 2 * y0:2 * (y0 + h), 2 * x0:2 * (x0 + w)].contiguous()
+            y = torch.stack([full[b, :, 2 * y0[b]:2 * (y0[b] + h), 2 * x0[b]:2 * (x0[b] + w)] for b in range(B)])
             TorchConvRec.window_calls += 1
+            TorchConvRec.mixed_origin_calls += int(len(set(zip(y0, x0))) > 1)
         else:
             if upsample2x:
                 x = F.interpolate(x, scale_factor=2.0, mode="nearest")
