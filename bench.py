@@ -10,7 +10,9 @@ One "step" = the whole hot path for ONE 8192x8192 image (latent 1024x1024, SDXL 
     then ONE tiled VAE decode of the latent (decoder tile 256 = upstream's default for > 30 GB, fast mode).
 The UNet itself is out of scope: the blend consumes pre-generated, HBM-resident tile outputs
 ~N(0,1); the VAE is an SD/SDXL-shaped decoder (ch=128, ch_mult 1-2-4-4) with seeded random weights (no checkpoints
-offline).  Inputs are resident in HBM before the timed region; nothing is cached between steps.
+offline).  Inputs are resident in HBM before the timed region; nothing is cached between steps.  In fast mode the decoder tiles shed the
+part of their padding that the remaining 3x3 convs cannot carry into the valid rectangle ("live-window narrowing", scripts/tilevae.py:
+live_windows; the assembled image is bit-identical to the whole-tile sweep; `config.vae_live_window`, MDTILE_LIVE_WINDOW=0 = whole tiles).
 
 N > 1: strong scaling of the same image -- diffusion tiles in row bands per rank with a neighbour halo exchange of the
 overlap-row partial sums, VAE tiles dealt round-robin, the fast-mode GroupNorm estimator split by rows across the ranks
@@ -570,7 +572,9 @@ def main():
                                    f"blend, {plan.num_tiles} tiles {plan.tile_w}x{plan.tile_h} overlap {plan.overlap}, N=2,C=4] + "
                                    + ("no VAE" if hook is None else f"tiled VAE decode (tile {args.vae_tile}, {'slow' if args.slow_vae else 'fast'} mode, SD decoder ch=128, random weights)"),
                        "latent": [L, L], "tile": [plan.tile_w, plan.tile_h], "overlap": plan.overlap, "evals": args.evals,
-                       "vae_tile": None if hook is None else args.vae_tile, "sharding": "none" if world == 1 else f"tile-row bands x{world} + halo exchange; VAE tiles round-robin, estimator split by rows, image gathered to rank 0 inside the step"},
+                       "vae_tile": None if hook is None else args.vae_tile,
+                       "vae_live_window": None if hook is None else bool(pl.tilevae.LIVE_WINDOW and not args.slow_vae),   # padded border the remaining convs cannot carry into the valid rectangle is not computed (same pixels, bit for bit)
+                       "sharding": "none" if world == 1 else f"tile-row bands x{world} + halo exchange; VAE tiles round-robin, estimator split by rows, image gathered to rank 0 inside the step"},
             "stage_ms": {"blend_eval": round(t_blend_eval * 1e3, 4), "vae_decode": None if t_vae is None else round(t_vae * 1e3, 2)},
             "stage_px_per_s": {"blend_eval": round(L * L / t_blend_eval, 1), "vae_decode": None if t_vae is None else round(L * L / t_vae, 1)},
             "value_f32": None if value_f32 is None else round(value_f32, 1), "ms_per_step_f32": None if ms_f32 is None else round(ms_f32, 2),
