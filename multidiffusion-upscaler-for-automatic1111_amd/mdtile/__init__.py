@@ -646,6 +646,25 @@ class RecImage:
         self.shape = (B, C, H, W)
         self.data = torch.empty(n // 4, dtype=torch.int32, device=device)
 
+    # the image is batch-major (rec[b][hl][C/8][H+2][W+2]): samples can be cut out of / stacked into it without touching the records
+    def batch_slice(self, b0: int, b1: int) -> "RecImage":
+        B, C, H, W = self.shape
+        assert 0 <= b0 < b1 <= B
+        per = self.data.numel() // B
+        r = RecImage.__new__(RecImage)
+        r.shape, r.data = (b1 - b0, C, H, W), self.data[b0 * per:b1 * per]
+        return r
+
+    @staticmethod
+    def cat(recs: Sequence["RecImage"]) -> "RecImage":
+        assert recs and all(r.shape[1:] == recs[0].shape[1:] for r in recs)
+        if len(recs) == 1:
+            return recs[0]
+        r = RecImage.__new__(RecImage)
+        r.shape = (sum(q.shape[0] for q in recs),) + tuple(recs[0].shape[1:])
+        r.data = torch.cat([q.data for q in recs])
+        return r
+
     def to_f32(self) -> torch.Tensor:
         B, C, H, W = self.shape
         out = torch.empty(self.shape, dtype=torch.float32, device=self.data.device)

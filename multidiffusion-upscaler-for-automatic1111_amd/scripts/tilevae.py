@@ -370,15 +370,20 @@ class VAEHook:
             return need_f32, "raw"
         return True, None
 
-    def _run_tile_rec(self, steps: List[Step], x: Tensor, frozen, coefs, norm_ord, windows=None) -> Tensor:
+    def _run_tile_rec(self, steps: List[Step], x: Tensor, frozen, coefs, norm_ord, windows=None, first: int = 0, last: Optional[int] = None,
+                      xrec=None):
         """One tile start to finish with frozen statistics (upstream's single sweep, :578-642).  A 3x3 conv that the record
         kernels take reads its input as a record image; whoever produces that input writes it in that form -- the previous
         record conv's epilogue (norm + SiLU + split fused), or mdtile_rec_from_f32 behind conv_in / attention.
-        windows (live_windows): the upsample convs listed there compute only that window of their input plane."""
+        windows (live_windows): the upsample convs listed there compute only that window of their input plane.
+        first / last / xrec: run steps[first:last] only; a sweep cut in front of an upsample conv (between two resblocks: no residual is
+        pending there) hands over (x, xrec) -- returned instead of x when `last` is given -- and is resumed with them."""
         E = self.engine
         res: List[Tensor] = []
-        xrec, pre = None, None
-        for i, s in enumerate(steps):
+        pre = None
+        stop = len(steps) if last is None else last
+        for i in range(first, stop):
+            s = steps[i]
             if s.kind == "store_res":
                 res.append(x if s.conv is None else s.conv(x))
             elif s.kind == "norm":
@@ -413,6 +418,9 @@ class VAEHook:
                 x, xrec = s.attn(x, res.pop()), None
             elif s.kind == "tanh":
                 x = E.tanh(x)
+        if last is not None:
+            assert not res and pre is None, "a sweep can only be cut between two resblocks"
+            return x, xrec
         return x
 
     def _live_plan(self, steps: List[Step], in_bbox, out_bbox):
@@ -628,54 +636,88 @@ class VAEHook:
                 # a conv launch over one tile fills the 256 CUs in ceil(items / 256) rounds and the last round is mostly empty
                 # (256 -> 256 at 1112^2: 4 900 items = 19.1 rounds, 4 % idle; 512 -> 512 at 278^2: 2.5 rounds, 16 % idle).
                 # 288 GB of HBM hold several tiles' activations at once (3 tiles of 278^2: ~40 GB).
-                # (stacked tiles share their launches: same shape AND live windows of the same SIZE -- each keeps its own window origin)
-                groups: Dict[tuple, List[int]] = {}
-                for i in mine:
-                    groups.setdefault(tuple(tiles[i].x.shape[2:]) + tuple((k, w[2], w[3]) for k, w in sorted(live[i][0].items())), []).append(i)
+                # With live windows the sweep is cut in front of a tile's first narrowed upsample conv: up to there tiles stack by SHAPE (the
+                # 1x level and the attention: small planes, where a fuller launch matters most), behind it by (plane, window SIZES) -- each
+                # tile keeps its own window origin, so the first and the last tile of a row share their launches.
+                cut = {i: (min(live[i][0]) if live[i][0] else None) for i in mine}
+                carry: Dict[int, tuple] = {}         # tile -> (x, xrec) in front of steps[cut]
 
-                def run_chunk(chunk):
-                    T = len(chunk)
+                def rep(T):
+                    return (frozen, coefs) if T == 1 else ([(v.repeat(T), m.repeat(T)) for v, m in frozen], [c.repeat(T, 1, 1) for c in coefs])
+
+                def regather(chunk):                 # inputs that were folded into a stacked copy: cut them out of z again
+                    for i in chunk:
+                        b = in_bboxes[i]
+                        tiles[i].x = E.gather_rect(z, b[0], b[2], b[1] - b[0], b[3] - b[2])
+
+                def head(chunk):
+                    T, k0 = len(chunk), cut[chunk[0]]
                     xb = tiles[chunk[0]].x if T == 1 else torch.cat([tiles[i].x for i in chunk], dim=0)
-                    fz = frozen if T == 1 else [(v.repeat(T), m.repeat(T)) for v, m in frozen]
-                    cf = coefs if T == 1 else [c.repeat(T, 1, 1) for c in coefs]
+                    fz, cf = rep(T)
                     if T > 1:
                         for i in chunk:
                             tiles[i].x = None          # the stacked copy is the live one
+                    if k0 is None:                     # nothing to shed: the whole sweep
+                        yb = self._run_tile_rec(steps, xb, fz, cf, norm_ord)
+                        for t, i in enumerate(chunk):
+                            tiles[i].x = yb[t * N:(t + 1) * N]
+                            finish(i)
+                        return
+                    xh, rh = self._run_tile_rec(steps, xb, fz, cf, norm_ord, None, 0, k0)
+                    for t, i in enumerate(chunk):
+                        carry[i] = (None if xh is None else xh[t * N:(t + 1) * N], None if rh is None else rh.batch_slice(t * N, (t + 1) * N))
+                        tiles[i].x = None
+
+                def tail(chunk):
+                    T, k0 = len(chunk), cut[chunk[0]]
+                    xs, rs = [carry[i][0] for i in chunk], [carry[i][1] for i in chunk]
+                    xb = None if xs[0] is None else (xs[0] if T == 1 else torch.cat(xs, dim=0))
+                    rb = None if rs[0] is None else type(rs[0]).cat(rs)
+                    fz, cf = rep(T)
                     wins = {k: ([live[i][0][k][0] for i in chunk for _ in range(N)], [live[i][0][k][1] for i in chunk for _ in range(N)], w[2], w[3])
                             for k, w in live[chunk[0]][0].items()}
-                    yb = self._run_tile_rec(steps, xb, fz, cf, norm_ord, wins)
+                    yb = self._run_tile_rec(steps, xb, fz, cf, norm_ord, wins, k0, None, rb)
                     for t, i in enumerate(chunk):
                         tiles[i].x = yb[t * N:(t + 1) * N]
+                        del carry[i]
                         finish(i)
 
-                for shape_key in sorted(groups, key=lambda kk: -len(groups[kk])):
-                    ids = groups[shape_key]
-                    # upstream sizes the TILE so that ONE tile's activations fit the card (:79-99); stacking is only taken when the
-                    # stacked sweep fits what is free right now, and a sweep that still runs out of memory is repeated tile by tile
-                    tb = self._tile_batch_that_fits(N, shape_key[:2], dev)
-                    if len(shape_key) > 2 and tb * N > 8:
-                        tb = max(1, 8 // N)        # mdtile_upconv2d_rec_window keeps 8 window origins per launch
-                    c0 = 0
-                    while c0 < len(ids):
-                        if state.interrupted:
-                            interrupted = True
-                            break
-                        chunk = ids[c0:c0 + tb]
-                        try:
-                            run_chunk(chunk)
-                        except torch.cuda.OutOfMemoryError:
-                            if len(chunk) == 1:
-                                raise
-                            print(f"[Tiled VAE]: {len(chunk)} stacked tiles do not fit in VRAM, continuing one tile per sweep")
-                            torch.cuda.empty_cache()
-                            for i in chunk:                # their inputs were folded into the stacked copy: cut them out of z again
-                                b = in_bboxes[i]
-                                tiles[i].x = E.gather_rect(z, b[0], b[2], b[1] - b[0], b[3] - b[2])
-                            tb = 1
-                            continue
-                        c0 += len(chunk)
-                    if interrupted:
-                        break
+                def sweep(groups, run_chunk, restore, origins: bool):
+                    nonlocal interrupted
+                    for key in sorted(groups, key=lambda kk: -len(groups[kk])):
+                        ids = groups[key]
+                        # upstream sizes the TILE so that ONE tile's activations fit the card (:79-99); stacking is only taken when the
+                        # stacked sweep fits what is free right now, and a sweep that still runs out of memory is repeated tile by tile
+                        tb = self._tile_batch_that_fits(N, key[:2], dev)
+                        if origins and tb * N > 8:
+                            tb = max(1, 8 // N)        # mdtile_upconv2d_rec_window keeps 8 window origins per launch
+                        c0 = 0
+                        while c0 < len(ids):
+                            if state.interrupted:
+                                interrupted = True
+                                return
+                            chunk = ids[c0:c0 + tb]
+                            try:
+                                run_chunk(chunk)
+                            except torch.cuda.OutOfMemoryError:
+                                if len(chunk) == 1:
+                                    raise
+                                print(f"[Tiled VAE]: {len(chunk)} stacked tiles do not fit in VRAM, continuing one tile per sweep")
+                                torch.cuda.empty_cache()
+                                restore(chunk)
+                                tb = 1
+                                continue
+                            c0 += len(chunk)
+
+                groups: Dict[tuple, List[int]] = {}
+                for i in mine:
+                    groups.setdefault(tuple(tiles[i].x.shape[2:]) + (cut[i],), []).append(i)
+                sweep(groups, head, regather, False)
+                if not interrupted and carry:
+                    groups = {}
+                    for i in sorted(carry):
+                        groups.setdefault(tuple(in_bboxes[i][k + 1] - in_bboxes[i][k] for k in (2, 0)) + tuple((k, w[2], w[3]) for k, w in sorted(live[i][0].items())), []).append(i)
+                    sweep(groups, tail, lambda chunk: None, True)      # (the carried planes of a failed stack are still there)
                 mine = []        # all done (or interrupted)
             for i in mine:
                 if state.interrupted:

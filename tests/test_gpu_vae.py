@@ -382,30 +382,35 @@ def test_tiled_decode_half_precision_vae(plugin, cuda):
     assert _rel(out.float().cpu(), ref) < 2e-3                          # + one fp16 rounding of the output
 
 
-def test_stacked_sweep_falls_back_to_single_tiles_on_oom(plugin, cuda, monkeypatch):
+@pytest.mark.parametrize("live,L,n_stacked,n_single", [(False, 64, 3, 9), (True, 80, 3 + 5, 16 + 16)], ids=["whole_tiles", "live_windows"])
+def test_stacked_sweep_falls_back_to_single_tiles_on_oom(plugin, cuda, monkeypatch, live, L, n_stacked, n_single):
     """Fast mode stacks tiles of one shape along the batch axis (TILE_BATCH); a stacked sweep that runs out of memory is repeated tile by
-    tile and the result is the same image (upstream sizes the tile for ONE tile's activations, scripts/tilevae.py:79-99)."""
+    tile and the result is the same image (upstream sizes the tile for ONE tile's activations, scripts/tilevae.py:79-99).
+    whole tiles, 64^2 latent at tile 16: 9 tiles = 4 of 38x38, 2 + 2 of 32x38 / 38x32, 1 of 32x32.
+    live windows, 80^2: 16 tiles; the sweep is cut in front of the first narrowed upsample conv: its head stacks by shape (9 + 3 + 3 + 1 tiles),
+    its tail by (shape, window sizes) = 4 inner tiles, 4 x 2 edge tiles, 4 x 1 corner tiles."""
     tv = plugin.tilevae
     dec = ld.make_decoder(4).to(cuda)
     dec.original_forward = dec.forward
     torch.manual_seed(17)
-    z = torch.randn(1, 4, 64, 64, device=cuda)          # 9 tiles: 4 of 38x38, 2 + 2 of 32x38 / 38x32, 1 of 32x32
+    z = torch.randn(1, 4, L, L, device=cuda)
     hook = tv.VAEHook(dec, 16, is_decoder=True, fast_decoder=True, fast_encoder=False, color_fix=False)
     monkeypatch.setattr(tv, "TILE_BATCH", 3)
+    monkeypatch.setattr(tv, "LIVE_WINDOW", live)
     ref = hook(z).clone()
     calls = {"stacked": 0, "single": 0}
     orig = tv.VAEHook._run_tile_rec
 
-    def flaky(self, steps, x, frozen, coefs, norm_ord):
-        if x.shape[0] > 1:
+    def flaky(self, steps, x, frozen, coefs, norm_ord, windows=None, first=0, last=None, xrec=None):
+        if (x if x is not None else xrec).shape[0] > 1:
             calls["stacked"] += 1
             raise torch.cuda.OutOfMemoryError("simulated")
         calls["single"] += 1
-        return orig(self, steps, x, frozen, coefs, norm_ord)
+        return orig(self, steps, x, frozen, coefs, norm_ord, windows, first, last, xrec)
 
     monkeypatch.setattr(tv.VAEHook, "_run_tile_rec", flaky)
     out = hook(z)
-    assert calls["stacked"] == 3 and calls["single"] == 9          # one failed stacked sweep per shape with > 1 tile, then all 9 tiles singly
+    assert calls["stacked"] == n_stacked and calls["single"] == n_single  # one failed stacked sweep per group with > 1 tile, then every tile singly
     assert torch.equal(out, ref)
     # the batch is also bounded by what is free: a tile that "needs" more than the card has gets batch 1
     assert hook._tile_batch_that_fits(1, (10 ** 5, 10 ** 5), cuda) == 1 and hook._tile_batch_that_fits(1, (16, 16), cuda) == 3

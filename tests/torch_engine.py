@@ -143,6 +143,13 @@ class TorchRec:
         self.t = t
         self.shape = tuple(t.shape)
 
+    def batch_slice(self, b0, b1):
+        return TorchRec(self.t[b0:b1])
+
+    @staticmethod
+    def cat(recs):
+        return recs[0] if len(recs) == 1 else TorchRec(torch.cat([r.t for r in recs], dim=0))
+
 
 class TorchConvRec(TorchConv):
     px_computed = 0      # output pixels x couts of every call_rec (what a narrowed sweep saves)
