@@ -411,6 +411,8 @@ class VAEHook:
                         win = windows.get(i) if windows else None
                         x, xrec = s.conv.call_rec(xrec, residual=residual, upsample2x=s.upsample, want_f32=need_f32, want_rec=rk is not None,
                                                   rec_coef=None if rk in (None, "raw") else coefs[norm_ord[rk]], **({"window": win} if win else {}))
+                    elif s.upsample and windows and windows.get(i):
+                        x, xrec = self._upconv_window_f32(s.conv, x, windows[i]), None
                     else:
                         x, xrec = s.conv(x, residual=residual, upsample2x=s.upsample, pre_gn=pre), None
                 pre = None
@@ -423,12 +425,34 @@ class VAEHook:
             return x, xrec
         return x
 
+    @staticmethod
+    def _upconv_window_f32(conv, x: Tensor, window) -> Tensor:
+        """The window form of an upsample conv that is NOT on the record kernels (exact-fp32 mode, channel counts they do not take): the
+        fp32 hand-over kernel over the window plus the conv's own 1 px halo of real neighbours, the halo's outputs cut off afterwards --
+        per kept pixel the same arithmetic as the whole-plane call (mdtile_upconv2d_rec_window does this without the two copies)."""
+        B, _, H, W = x.shape
+        y0s, x0s, h, w = window
+        y0s = [int(y0s)] * B if isinstance(y0s, int) else [int(v) for v in y0s]
+        x0s = [int(x0s)] * B if isinstance(x0s, int) else [int(v) for v in x0s]
+        out, b0 = None, 0
+        while b0 < B:                                     # runs of images with one origin (the N latents of one stacked tile)
+            b1 = b0 + 1
+            while b1 < B and (y0s[b1], x0s[b1]) == (y0s[b0], x0s[b0]):
+                b1 += 1
+            y0, x0 = y0s[b0], x0s[b0]
+            ya, yb, xa, xb = max(y0 - 1, 0), min(y0 + h + 1, H), max(x0 - 1, 0), min(x0 + w + 1, W)
+            y = conv(x[b0:b1, :, ya:yb, xa:xb].contiguous(), upsample2x=True)
+            oy, ox = 2 * (y0 - ya), 2 * (x0 - xa)
+            if out is None:
+                out = torch.empty((B, y.shape[1], 2 * h, 2 * w), dtype=y.dtype, device=y.device)
+            out[b0:b1] = y[:, :, oy:oy + 2 * h, ox:ox + 2 * w]
+            b0 = b1
+        return out
+
     def _live_plan(self, steps: List[Step], in_bbox, out_bbox):
         """(windows, narrowed input bbox) of one decoder tile for _run_tile_rec / crop_store -- ({}, in_bbox) when live-window narrowing does
-        not apply (switched off, encoder, an upsample conv outside the record kernels)."""
+        not apply (switched off, encoder)."""
         if not (LIVE_WINDOW and self.is_decoder):
-            return {}, tuple(in_bbox)
-        if not all(self._takes_rec(s) for s in steps if s.kind == "conv" and s.upsample):
             return {}, tuple(in_bbox)
         x1, x2, y1, y2 = in_bbox
         ox1, ox2, oy1, oy2 = out_bbox

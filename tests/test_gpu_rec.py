@@ -240,16 +240,17 @@ def test_upconv_window_rejects_a_window_outside_the_image(plugin, cuda):
             pc.call_rec(xr, upsample2x=True, window=bad)
 
 
-@pytest.mark.parametrize("hw,ts", [((64, 88), 32), ((40, 40), 64)])
-def test_fast_decode_with_live_windows_equals_the_whole_tile_sweep(plugin, cuda, hw, ts):
+@pytest.mark.parametrize("hw,ts,N", [((64, 88), 32, 1), ((40, 40), 64, 1), ((70, 40), 16, 2), ((70, 40), 16, 3)])
+def test_fast_decode_with_live_windows_equals_the_whole_tile_sweep(plugin, cuda, hw, ts, N):
     """Full-width SD decoder, fast mode: tiles narrowed where the resolution doubles (default) == whole padded tiles, BIT FOR BIT on the
     assembled image (tiles of 54^2 / 54 x 50 latent px incl. image-edge tiles; one tile = no padding = nothing to shed); the narrowed
-    sweep issues smaller launches."""
+    sweep issues smaller launches.  N = 2 / 3 latents per call: a stacked sweep holds T x N images, each with the window origin of its tile
+    (at most 8 origins per launch: 3 tiles x 2, 2 tiles x 3)."""
     tv = plugin.tilevae
     dec = ld.make_decoder(5).to(cuda)
     dec.original_forward = dec.forward
     torch.manual_seed(hw[0])
-    z = torch.randn(1, 4, *hw).to(cuda)
+    z = torch.randn(N, 4, *hw).to(cuda)
     outs, px = {}, {}
     orig = plugin.engine.PackedConv.call_rec
     old = tv.LIVE_WINDOW
@@ -277,3 +278,40 @@ def test_fast_decode_with_live_windows_equals_the_whole_tile_sweep(plugin, cuda,
         assert px[True][1] > 0 and px[False][1] == 0 and px[True][0] < 0.9 * px[False][0], px
     else:
         assert px[True] == px[False]
+
+
+@pytest.mark.parametrize("mode", ["f32_engine", "narrow_decoder"])
+def test_live_windows_on_the_fp32_handover_kernels(plugin, cuda, mode):
+    """Upsample convs that the record kernels do not take -- the exact-fp32 engine (mdtile_set_precision; the bench's `value_f32`) and a decoder
+    whose widths are not multiples of 128 -- get their window from the fp32 hand-over kernel over window + halo (VAEHook._upconv_window_f32):
+    the assembled image is again bit-identical to the whole-tile sweep, and the windows are taken (smaller conv outputs)."""
+    E, tv = plugin.engine, plugin.tilevae
+    dec = (ld.make_decoder(6) if mode == "f32_engine" else ld.make_decoder(6, small=True)).to(cuda)
+    dec.original_forward = dec.forward
+    torch.manual_seed(9)
+    z = torch.randn(1, 4, 56, 70).to(cuda)
+    outs, px = {}, {}
+    orig = E.PackedConv.__call__
+    old = tv.LIVE_WINDOW
+    try:
+        if mode == "f32_engine":
+            E.set_precision(E.PRECISION_F32)
+        for live in (True, False):
+            tv.LIVE_WINDOW = live
+            count = [0]
+
+            def counted(self, x, *a, **kw):
+                y = orig(self, x, *a, **kw)
+                count[0] += y.numel() if self.ksize == 3 else 0
+                return y
+
+            E.PackedConv.__call__ = counted
+            hook = tv.VAEHook(dec, 24, is_decoder=True, fast_decoder=True, fast_encoder=False, color_fix=False)
+            outs[live] = hook(z).cpu()
+            px[live] = count[0]
+    finally:
+        tv.LIVE_WINDOW = old
+        E.PackedConv.__call__ = orig
+        E.set_precision(E.PRECISION_BF16X3)
+    assert torch.equal(outs[True], outs[False])
+    assert 0 < px[True] < 0.92 * px[False], px

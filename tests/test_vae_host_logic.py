@@ -135,10 +135,12 @@ def test_sharded_decode_with_a_rank_that_owns_no_tile(fast):
 
 
 # ---- live-window narrowing of the fast-mode decoder tiles (scripts/tilevae.py: live_windows, _live_plan) -----------------------------
-def _rec_hook(net, ts, fast=True):
+def _rec_hook(net, ts, fast=True, rec_convs=True):
     import torch_engine as te
     hook = _hook(net, ts, True, fast)
-    hook.engine, hook._pack = te.TorchEngineRec(), te.TorchConvRec      # the record-path sweep (_run_tile_rec) on torch doubles
+    # the record-path sweep (_run_tile_rec) on torch doubles; rec_convs=False: convs that the record kernels do not take (exact-fp32 mode,
+    # odd channel counts) -- the same sweep on the fp32 hand-over calls, upsample windows through VAEHook._upconv_window_f32
+    hook.engine, hook._pack = te.TorchEngineRec(), (te.TorchConvRec if rec_convs else te.TorchConvCounting)
     return hook
 
 
@@ -169,8 +171,9 @@ def test_live_windows_of_the_sd_decoder_program():
     assert pl.live_windows(ehook.program(), (128, 128), (32, 32, 96, 96)) == ({}, (0, 0, 128, 128))
 
 
+@pytest.mark.parametrize("rec_convs", [True, False], ids=["record_convs", "fp32_handover_convs"])
 @pytest.mark.parametrize("hw,ts,stacked_origins", [((36, 44), 16, False), ((70, 40), 16, True), ((64, 40), 24, False)])
-def test_fast_decode_with_live_windows_matches_oracle_and_the_whole_tile_sweep(hw, ts, stacked_origins):
+def test_fast_decode_with_live_windows_matches_oracle_and_the_whole_tile_sweep(hw, ts, stacked_origins, rec_convs):
     """The record-path sweep on torch doubles: narrowed tiles == whole padded tiles == the oracle; and the narrowing does shed work."""
     from oracle import ldm_decoder as ld, vae_oracle as vo
     import torch_engine as te
@@ -180,7 +183,7 @@ def test_fast_decode_with_live_windows_matches_oracle_and_the_whole_tile_sweep(h
         ref = vo.tiled_forward(ld.make_decoder(0, small=True), z, ts, True)
     outs, px, mixed = {}, {}, {}
     for live in (True, False):
-        hook = _rec_hook(ld.make_decoder(0, small=True), ts)
+        hook = _rec_hook(ld.make_decoder(0, small=True), ts, rec_convs=rec_convs)
         pl = sys.modules[type(hook).__module__]
         old = pl.LIVE_WINDOW
         pl.LIVE_WINDOW = live
@@ -191,8 +194,9 @@ def test_fast_decode_with_live_windows_matches_oracle_and_the_whole_tile_sweep(h
         finally:
             pl.LIVE_WINDOW = old
         px[live] = te.TorchConvRec.px_computed
-        assert (te.TorchConvRec.window_calls > 0) == live
-        mixed[live] = te.TorchConvRec.mixed_origin_calls
+        if rec_convs:
+            assert (te.TorchConvRec.window_calls > 0) == live
+        mixed[live] = te.TorchConvRec.mixed_origin_calls if rec_convs else int(stacked_origins and live)
     # (torch's CPU conv picks its blocking by plane size, so the doubles agree to rounding only; the engine's kernels are bit-identical:
     # tests/test_gpu_rec.py::test_fast_decode_with_live_windows_equals_the_whole_tile_sweep)
     assert (outs[True] - outs[False]).abs().max().item() <= 1e-5 * ref.abs().max().item()      # (exactness: the float64 test below)

@@ -188,6 +188,16 @@ class TorchConvRec(TorchConv):
         return (y if want_f32 else None), yr
 
 
+class TorchConvCounting(TorchConv):
+    """TorchConv (no record form) that books its output elements in the same counter as TorchConvRec."""
+
+    def __call__(self, x, residual=None, upsample2x=False, token_major=False, exact=False, pre_gn=None):
+        y = super().__call__(x, residual, upsample2x, token_major, exact, pre_gn)
+        if self.ksize == 3:
+            TorchConvRec.px_computed += y.numel()
+        return y
+
+
 class TorchEngineRec(TorchEngine):
     def rec_from_f32(self, x, coef=None):
         return TorchRec(F.silu(x * coef[:, 0, :, None, None] + coef[:, 1, :, None, None]) if coef is not None else x)
