@@ -13,6 +13,7 @@ The UNet itself is out of scope: the blend consumes pre-ge
 offline).  Inputs are resident in HBM before the timed region; nothing is cached between steps.  In fast mode the decoder tiles shed the
 part of their padding that the remaining 3x3 convs cannot carry into the valid rectangle ("live-window narrowing", scripts/tilevae.py:
 live_windows; the assembled image is bit-identical to the whole-tile sweep; `config.vae_live_window`, MDTILE_LIVE_WINDOW=0 = whole tiles).
+`whole_tiles` in the JSON line is the same step timed with the narrowing off, with `bit_identical_image` = torch.equal of the two 8K images.
 
 N > 1: strong scaling of the same image -- diffusion tiles in row bands per rank with a neighbour halo exchange of the
 overlap-row partial sums, VAE tiles dealt round-robin, the fast-mode GroupNorm estimator split by rows across the ranks
@@ -65,6 +66,7 @@ def parse():
     ap.add_argument("--slow-vae", action="store_true", help="slow-mode GroupNorm (pooled per norm) instead of fast mode")
     ap.add_argument("--no-vae", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-whole-tile-pass", action="store_true", help="skip the companion step with the live-window narrowing off (whole_tiles in the JSON line)")
     ap.add_argument("--no-f32-pass", action="store_true", help="skip the strict-fp32 companion decode (parity.rel_err_vs_f32, value_f32)")
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the per-stage split and the HIP-event roofline pass (PMC runs)")
     ap.add_argument("--no-oracle-pass", action="store_true", help="skip parity.rel_err_vs_oracle (assembled cfg3 decode vs the oracle on the GPU, untimed)")
@@ -455,6 +457,30 @@ def main():
                 rl["clock_GHz_measured"] = round(sum(h["clock_GHz"] * h["dispatches"] for h in ck) / max(1, sum(h["dispatches"] for h in ck)), 3)
                 rl["clock_source"] = "GRBM_GUI_ACTIVE / 8 XCDs / kernel duration in the FETCH_SIZE pass; `peak` is quoted at 2.4 GHz"
 
+    # ------------------------------------------------------------------ whole-tile companion: the same step with the live-window narrowing OFF
+    # (every padded tile decoded whole, as upstream does; untimed region of the headline, its own clock).  The two assembled images must be
+    # the SAME numbers: the narrowing only leaves out pixels that crop_valid_region would throw away and that no kept pixel can see.
+    whole = None
+    if rank == 0 and world == 1 and hook is not None and not args.no_whole_tile_pass and pl.tilevae.LIVE_WINDOW and not args.slow_vae:
+        builtins.print = lambda *a, **k: None
+        try:
+            img_live = hook(z)
+            pl.tilevae.LIVE_WINDOW = False
+            hook(z)                                  # warm
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.evals):
+                blend_eval()
+            img_whole = hook(z)
+            torch.cuda.synchronize()
+            ms_whole = (time.perf_counter() - t0) * 1e3
+        finally:
+            pl.tilevae.LIVE_WINDOW = True
+            builtins.print = _print
+        whole = {"ms_per_step": round(ms_whole, 2), "value": round(L * L / (ms_whole * 1e-3), 1), "bit_identical_image": bool(torch.equal(img_live, img_whole)),
+                 "what": "same step with MDTILE_LIVE_WINDOW=0 (every padded decoder tile computed whole, like upstream) and torch.equal of the two 8K images"}
+        del img_live, img_whole
+
     # ------------------------------------------------------------------ strict-fp32 companion: same decode on the exact-fp32 MFMA kernels
     # (untimed region of the headline; its own clock).  `parity.rel_err_vs_f32` = max |bf16x3 - f32| / max |f32| over the whole image.
     parity = value_f32 = ms_f32 = None
@@ -577,6 +603,7 @@ def main():
                        "sharding": "none" if world == 1 else f"tile-row bands x{world} + halo exchange; VAE tiles round-robin, estimator split by rows, image gathered to rank 0 inside the step"},
             "stage_ms": {"blend_eval": round(t_blend_eval * 1e3, 4), "vae_decode": None if t_vae is None else round(t_vae * 1e3, 2)},
             "stage_px_per_s": {"blend_eval": round(L * L / t_blend_eval, 1), "vae_decode": None if t_vae is None else round(L * L / t_vae, 1)},
+            "whole_tiles": whole,
             "value_f32": None if value_f32 is None else round(value_f32, 1), "ms_per_step_f32": None if ms_f32 is None else round(ms_f32, 2),
             "parity": parity,
             "roofline": roofline, "roofline_blend": roofline_blend, "roofline_blend_f16": roofline_blend_f16, "cpu_baseline": cpu_baseline,
