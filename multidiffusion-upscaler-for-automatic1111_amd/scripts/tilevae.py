@@ -412,6 +412,7 @@ class VAEHook:
                         x, xrec = s.conv.call_rec(xrec, residual=residual, upsample2x=s.upsample, want_f32=need_f32, want_rec=rk is not None,
                                                   rec_coef=None if rk in (None, "raw") else coefs[norm_ord[rk]], **({"window": win} if win else {}))
                     elif s.upsample and windows and windows.get(i):
+                        assert residual is None and pre is None      # ldm Upsample: no norm in front, no skip connection into it
                         x, xrec = self._upconv_window_f32(s.conv, x, windows[i]), None
                     else:
                         x, xrec = s.conv(x, residual=residual, upsample2x=s.upsample, pre_gn=pre), None
