@@ -134,7 +134,7 @@ def main():
         ge.build()
     if world > 1:
         dist.barrier()
-    from oracle import stub_host as sh   # stub A1111 host (test infra) to drive the plugin without a webui
+    from hostsim import stub_host as sh   # stand-in A1111 host: drives the plugin without a webui (no arithmetic of the path; hostsim/, not oracle/)
     sh.install(dev)
     sh.set_device(dev)
     pl = sh.load_plugin()
@@ -166,7 +166,7 @@ def main():
                     transport = "rccl (torch.distributed nccl group)"
                 else:
                     transport = "gloo (host-staged: neither RCCL communicator came up)"
-    from oracle import ldm_decoder as ld  # only for the random-weight SD-shaped decoder definition
+    from hostsim import ldm_decoder as ld  # the random-weight SD-shaped decoder definition (the nn.Module the hook is attached to)
 
     L, N, C = args.latent, 2, 4
     method = E.METHOD_MD if args.method == "md" else E.METHOD_MOD

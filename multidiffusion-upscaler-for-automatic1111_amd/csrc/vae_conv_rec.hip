@@ -36,212 +36,9 @@
 
 using namespace mdt;
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#include "conv_rec_common.h"
 
 namespace {
-
-constexpr int REC_WIN_MAXB = 8;   // images per launch that may carry a window origin of their own (stacked tiles of one shape)
-
-struct ConvRParams {
-    const u32x4* x;      // input record image [B][2][Cin/8][Hin+2][Win+2]
-    const u32x4* w;      // packed weights (vae_conv_bf16x3.hip: k_conv_pack_bf16x3 / k_upconv_pack_bf16x3, permuted K order)
-    const float* bias;   // [Cout] or null
-    const float* res;    // residual [B, Cout, H, W] fp32 or null
-    float* y32;          // fp32 output [B, Cout, H, W] or null
-    u32x4* yrec;         // record-image output [B][2][Cout/8][H+2][W+2] or null
-    const float* coef;   // activation of the record output: [B][2][Cout] = (a, s), yrec = split(silu(a y + s)); null = split(y)
-    int B, Cin, Cout, H, W;   // H, W: OUTPUT size
-    int Hin, Win;             // input size (= H, W; half of it for the sub-pixel upsample kernel)
-    int HinF, WinF;           // sub-pixel upsample kernel: image b's input is the window [iy0[b] : iy0[b] + Hin, ix0[b] : ix0[b] + Win] of a
-    int iy0[REC_WIN_MAXB], ix0[REC_WIN_MAXB];   // record image of HinF x WinF px (whole image: HinF = Hin, WinF = Win, all origins 0)
-    int ptiles, PX, NCB, NK;  // pixel tiles, tiles per row, cout blocks, 16-channel K-steps
-};
-
-__device__ __forceinline__ void split8r(const float (&v)[8], u32x4& hi, u32x4& lo) {
-    bf16x8 h, l;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        h[i] = (__bf16)v[i];
-        l[i] = (__bf16)(v[i] - (float)h[i]);
-    }
-    hi = __builtin_bit_cast(u32x4, h);
-    lo = __builtin_bit_cast(u32x4, l);
-}
-
-// LDS-DMA of one 16-byte record per lane: global (scalar base + 32-bit lane offset) -> LDS (wave-uniform base + 16 * lane).
-// Issued through inline asm on purpose: hipcc books a __builtin_amdgcn_global_load_lds as a pending FLAT access and then
-// degrades EVERY later `s_waitcnt lgkmcnt(N)` to lgkmcnt(0) -- the fragment prefetch below would wait for the reads it has
-// just issued.  The asm is invisible to that bookkeeping; its completion is counted by hand (vmcnt(0) + barrier before any
-// ds_read of the data).  M0 = LDS destination, restored afterwards (compiler-reserved); s_nop: M0 / SGPR-base write -> VMEM read.
-__device__ __forceinline__ void dma16(const char* base, unsigned voff, const u32x4* lds_dst) {
-    const unsigned l = (unsigned)(__UINTPTR_TYPE__)(const __attribute__((address_space(3))) u32x4*)lds_dst;
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(base), "s"(l)
-                 : "memory");
-}
-
-__device__ __forceinline__ float silu_f(float t) { return t * __builtin_amdgcn_rcpf(1.0f + __expf(-t)); }
-
-// ---- shared epilogue: one 32-cout tile of a wave (NROW pixel rows x NPX pixels per lane) -> + bias (+ residual) -> fp32 NCHW
-// and / or record image.  C/D layout of a 32x32 MFMA: col = lane & 31 (pixel), row = (q&3) + 8*(q>>2) + 4*(lane>>5) (cout).
-// The epilogue is latency-, not bandwidth-bound (one block per CU, nothing else to run meanwhile), so it is built to expose
-// as few memory round trips as possible:
-//   * the per-channel constants (bias, and the (a, s) of the record output's activation) of the item's 128 couts are DMA'd
-//     into a 3 x 1 KB LDS buffer together with the item's first operands -- the epilogue reads them with ds_read_b128;
-//   * the residual is requested 32 values per lane at a time (two pixel rows) before the first of them is used.
-struct EpiCtx {
-    const float* __restrict__ res;
-    float* __restrict__ y32;
-    u32x4* __restrict__ yrec;
-    bool has_bias, has_act;
-    int Cout, H, W;      // output size
-    int b, kg;
-    size_t HW, planeO;   // fp32 plane, record plane ((H+2)*(W+2))
-    int WpO;
-};
-
-constexpr int EC_REC = 3 * 64;   // records of one constants buffer: [bias | a | s] x 1 KB (128 floats + pad for the DMA's upper lanes)
-
-template <int NPX, int NROW>   // NPX = 1: one pixel per lane; NPX = 2: the lane owns output px (2X, 2X+1) (sub-pixel upsample kernel)
-__device__ __forceinline__ void epilogue_mtile(const EpiCtx& E, const u32x4* ec, f32x16 (&acc)[NROW][NPX], int mt_local, int mt_global,
-                                               const int (&ys)[NROW], int x, bool x_ok) {
-    // constants of this lane's 16 couts: q = 4 g + i  <->  channel 32 mt + 4 kg + 8 g + i
-    float bq[16], aq[16], sq[16];
-    {
-        const float4* e4 = reinterpret_cast<const float4*>(ec);
-        const int c4 = (mt_local * 32 + 4 * E.kg) >> 2;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 tb = E.has_bias ? e4[c4 + 2 * g] : make_float4(0.f, 0.f, 0.f, 0.f);
-            bq[4 * g] = tb.x; bq[4 * g + 1] = tb.y; bq[4 * g + 2] = tb.z; bq[4 * g + 3] = tb.w;
-            if (E.has_act) {
-                const float4 ta = e4[64 + c4 + 2 * g], ts = e4[128 + c4 + 2 * g];   // slots of 64 float4 (1 KB)
-                aq[4 * g] = ta.x; aq[4 * g + 1] = ta.y; aq[4 * g + 2] = ta.z; aq[4 * g + 3] = ta.w;
-                sq[4 * g] = ts.x; sq[4 * g + 1] = ts.y; sq[4 * g + 2] = ts.z; sq[4 * g + 3] = ts.w;
-            }
-        }
-    }
-    const int cbase = mt_global * 32 + 4 * E.kg;
-    const size_t obase = ((size_t)E.b * E.Cout + cbase) * E.HW;
-    const int xc = x_ok ? x : 0;                                  // clamped column for the unconditional residual loads
-#pragma unroll
-    for (int n = 0; n < NROW; ++n)
-#pragma unroll
-        for (int e = 0; e < NPX; ++e)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[n][e][q] += bq[q];
-    if (E.res) {
-        constexpr int RB = NPX == 1 ? 2 : 1;      // rows whose residual is in flight together (32 registers)
-#pragma unroll
-        for (int n0 = 0; n0 < NROW; n0 += RB) {
-            float r[RB][NPX][16];
-#pragma unroll
-            for (int n = 0; n < RB; ++n) {
-                const int yc = ys[n0 + n] < E.H ? ys[n0 + n] : E.H - 1;
-                const float* rp0 = E.res + obase + (size_t)yc * E.W + xc;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const float* rp = rp0 + (size_t)((q & 3) + 8 * (q >> 2)) * E.HW;
-                    if (NPX == 2) {
-                        const float2 r2 = *reinterpret_cast<const float2*>(rp);
-                        r[n][0][q] = r2.x;
-                        r[n][NPX - 1][q] = r2.y;
-                    } else {
-                        r[n][0][q] = *rp;
-                    }
-                }
-            }
-#pragma unroll
-            for (int n = 0; n < RB; ++n)
-#pragma unroll
-                for (int e = 0; e < NPX; ++e)
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) acc[n0 + n][e][q] += r[n][e][q];
-        }
-    }
-#pragma unroll
-    for (int n = 0; n < NROW; ++n) {
-        const int y = ys[n];
-        if (!(y < E.H && x_ok)) continue;
-        const size_t o0 = obase + (size_t)y * E.W + x;
-        if (E.y32) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                if (cbase + (q & 3) + 8 * (q >> 2) >= E.Cout) continue;          // narrow convs: couts past Cout are padding
-                float* yp = E.y32 + o0 + (size_t)((q & 3) + 8 * (q >> 2)) * E.HW;
-                if (NPX == 2) *reinterpret_cast<float2*>(yp) = make_float2(acc[n][0][q], acc[n][NPX - 1][q]);
-                else *yp = acc[n][0][q];
-            }
-        }
-        if (E.yrec) {
-            // records R = 0 (q 0..7) and R = 1 (q 8..15) of this lane: planes ((mt*2 + R)*2 + kg)
-            const int Pn = E.Cout >> 3;
-            u32x4* yb = E.yrec + (size_t)E.b * 2 * Pn * E.planeO;
-#pragma unroll
-            for (int R = 0; R < 2; ++R) {
-                const size_t pl = (size_t)((mt_global * 2 + R) * 2 + E.kg) * E.planeO;
-#pragma unroll
-                for (int e = 0; e < NPX; ++e) {
-                    float t8[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float t = acc[n][e][8 * R + j];
-                        t8[j] = E.has_act ? silu_f(fmaf(t, aq[8 * R + j], sq[8 * R + j])) : t;
-                    }
-                    u32x4 hi, lo;
-                    split8r(t8, hi, lo);
-                    const size_t at = pl + (size_t)(y + 1) * E.WpO + (x + e + 1);
-                    yb[at] = hi;
-                    yb[(size_t)Pn * E.planeO + at] = lo;
-                }
-                // zero border of the record image (this block owns the border cells next to its edge pixels)
-                const bool left = x == 0, right = x + NPX == E.W, top = y == 0, bot = y == E.H - 1;
-                if (left || right || top || bot) {
-                    const u32x4 z = {0u, 0u, 0u, 0u};
-                    auto zrec = [&](int py, int px) {
-                        const size_t at = pl + (size_t)py * E.WpO + px;
-                        yb[at] = z;
-                        yb[(size_t)Pn * E.planeO + at] = z;
-                    };
-                    if (left) zrec(y + 1, 0);
-                    if (right) zrec(y + 1, E.W + 1);
-                    if (top) {
-#pragma unroll
-                        for (int e = 0; e < NPX; ++e) zrec(0, x + e + 1);
-                        if (left) zrec(0, 0);
-                        if (right) zrec(0, E.W + 1);
-                    }
-                    if (bot) {
-#pragma unroll
-                        for (int e = 0; e < NPX; ++e) zrec(E.H + 1, x + e + 1);
-                        if (left) zrec(E.H + 1, 0);
-                        if (right) zrec(E.H + 1, E.W + 1);
-                    }
-                }
-            }
-        }
-    }
-}
-
-#define MDT_PIN() __builtin_amdgcn_sched_barrier(0)
-
-// =====================================================================================================================
-// LDS input stage shared by both kernels: [hl][kg][ROWS][34] records, each hl half padded to whole 64-record DMA pieces so
-// that one wave-instruction never straddles the two halves (hl then sits in the scalar base address, the lane offset
-// stays 32-bit: global_load_lds with saddr + voffset).
-template <int ROWS>
-struct InStage {
-    static constexpr int COLS = 34;
-    static constexpr int HALF = 2 * ROWS * COLS;               // records of one hl half
-    static constexpr int HALF_DMA = (HALF + 63) / 64;           // wave-instructions per half
-    static constexpr int HALF_PAD = HALF_DMA * 64;
-    static constexpr int DMA = 2 * HALF_DMA, PAD = 2 * HALF_PAD;
-    static constexpr int PW = (DMA + 7) / 8;                    // wave-instructions per wave
-};
 
 // One unit of work of a persistent block: a (batch sample, pixel tile, cout block) triple.
 struct WorkItem {
@@ -458,9 +255,11 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rec(const ConvRParams P) {
         int ys[NROW];
 #pragma unroll
         for (int n = 0; n < NROW; ++n) ys[n] = cur.y0 + wr * NROW + n;
+        if (!(P.dbg & 1)) {
 #pragma unroll
-        for (int m = 0; m < MW; ++m)
-            epilogue_mtile<1, NROW>(E, ec_l + par * EC_REC, acc[m], wm * MW + m, cur.cb * MT + wm * MW + m, ys, x, x < P.W);
+            for (int m = 0; m < MW; ++m)
+                epilogue_mtile<1, NROW>(E, ec_l + par * EC_REC, acc[m], wm * MW + m, cur.cb * MT + wm * MW + m, ys, x, x < P.W);
+        }
         if (work_n >= total) break;
         work = work_n;
         cur = nxt;
@@ -679,9 +478,11 @@ __global__ __launch_bounds__(512, 2) void k_upconv_rec(const ConvRParams P) {
             const int yi = cur.y0 + wr * NROW + n;
             ys[n] = yi < P.Hin ? 2 * yi + cur.a : P.H;      // rows past the input's last row: marked invalid
         }
+        if (!(P.dbg & 1)) {
 #pragma unroll
-        for (int m = 0; m < MW; ++m)
-            epilogue_mtile<2, NROW>(E, ec_l + par * EC_REC, acc[m], wm * MW + m, cur.cb * MT + wm * MW + m, ys, 2 * xi, xi < P.Win);
+            for (int m = 0; m < MW; ++m)
+                epilogue_mtile<2, NROW>(E, ec_l + par * EC_REC, acc[m], wm * MW + m, cur.cb * MT + wm * MW + m, ys, 2 * xi, xi < P.Win);
+        }
         if (work_n >= total) break;
         work = work_n;
         cur = nxt;
@@ -752,7 +553,12 @@ static bool rec_persistent() {
     return !(e && e[0] == '0');
 }
 
+// MDTILE_REC_GRID=n: probing -- the persistent kernels run as if the chip had n CUs (n % 8 == 0)
 static int num_cus() {
+    if (const char* e = getenv("MDTILE_REC_GRID")) {
+        const int n = atoi(e);
+        if (n >= 8) return n / 8 * 8;
+    }
     static const int n = [] {
         int dev = 0, cus = 256;
         hipDeviceProp_t prop;
@@ -761,6 +567,15 @@ static int num_cus() {
         return cus;
     }();
     return n;
+}
+
+// vae_conv_rec2.hip: the two-blocks-per-CU form of the cout % 128 == 0 kernels
+int conv_rec2_launch(ConvRParams P, int B, int up, hipStream_t s, int cus);
+
+// MDTILE_REC_BLOCKS=1: the one-block-per-CU kernels of this file for every shape (A/B against vae_conv_rec2.hip; read per launch)
+static bool rec_two_blocks() {
+    const char* e = getenv("MDTILE_REC_BLOCKS");
+    return !(e && e[0] == '1');
 }
 
 bool conv_rec_supported(int cout, int cin, int ksize) { return ksize == 3 && cin % 32 == 0 && (cout % 128 == 0 || (cout >= 1 && cout < 32)); }
@@ -797,8 +612,12 @@ int conv_rec_launch(const void* d_xrec, const void* d_w_rec, const float* d_bias
     }
     P.NCB = cout % 128 == 0 ? cout / 128 : 1;
     P.NK = cin / 16;
+    P.skew_ticks = 0; P.cu_ctr = nullptr; P.census = nullptr;
+    P.dbg = 0;
+    if (const char* e = getenv("MDTILE_REC_DBG")) P.dbg = atoi(e);      // probing only (probes/conv_rec2_ab.py): see ConvRParams::dbg
+    if (up) P.w = (const u32x4*)d_w_rec + conv_bf16x3_direct_records(cout, cin);
+    if (cout % 128 == 0 && rec_persistent() && rec_two_blocks()) return conv_rec2_launch(P, B, up, s, num_cus());
     if (up) {
-        P.w = (const u32x4*)d_w_rec + conv_bf16x3_direct_records(cout, cin);
         P.PX = (P.Win + 31) / 32;
         P.ptiles = P.PX * ((P.Hin + 7) / 8);
         const long long items = (long long)((P.ptiles + 7) / 8) * 8 * P.NCB * 2 * B;

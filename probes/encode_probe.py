@@ -6,7 +6,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "multidiffusion-upscaler-for-automatic1111_amd"))
-from oracle import stub_host as sh, ldm_decoder as ld   # stub A1111 host + the random-weight encoder definition (test infra)
+from hostsim import stub_host as sh, ldm_decoder as ld   # stub A1111 host + the random-weight encoder definition (test infra)
 
 side = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 tile = int(sys.argv[2]) if len(sys.argv) > 2 else 3072

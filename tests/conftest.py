@@ -44,13 +44,13 @@ def built_lib():
     """libmdtile.so, (re)built in-tree if the sources changed (hipcc cross-compiles without a GPU)."""
     import __graft_entry__ as ge
     ge.build()
-    from oracle import stub_host
+    from hostsim import stub_host
     return stub_host.load_plugin().engine
 
 
 @pytest.fixture(scope="session")
 def plugin(built_lib):
-    from oracle import stub_host
+    from hostsim import stub_host
     dev = "cuda" if torch.cuda.is_available() else "cpu"
     stub_host.install(dev)
     stub_host.set_device(dev)

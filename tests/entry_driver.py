@@ -13,7 +13,7 @@ import torch
 
 from oracle import blend_oracle as bo
 from oracle import entry_oracle as eo
-from oracle import stub_host as sh
+from hostsim import stub_host as sh
 
 REGIONS = [  # fractions of the canvas, BBoxSettings style
     (0.0, 0.0, 0.45, 1.0, "Background", 0.2),

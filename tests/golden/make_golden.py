@@ -22,9 +22,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
-from oracle import stub_host as sh  # noqa: E402
+from hostsim import stub_host as sh  # noqa: E402
 from oracle import blend_oracle as bo  # noqa: E402  (only for the synthetic denoisers + region_rect helper)
-from oracle import ldm_decoder as ld  # noqa: E402
+from hostsim import ldm_decoder as ld  # noqa: E402
 
 REGIONS_CFG5 = [  # fractions of the canvas, as in BBoxSettings
     (0.0, 0.0, 0.4, 1.0, "Background", 0.2),

@@ -13,7 +13,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
-from oracle import ldm_decoder as ld, stub_host as sh  # noqa: E402
+from hostsim import ldm_decoder as ld, stub_host as sh  # noqa: E402
 
 ENC_CASES = [   # image (not latent) sizes; small encoder (ch=32, same topology as SD's)
     dict(name="enc_fast", H=160, W=192, ts=64, fast=True, color_fix=False, seed=4, enc_seed=0),

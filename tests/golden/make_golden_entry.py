@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 
-from oracle import stub_host as sh  # noqa: E402
+from hostsim import stub_host as sh  # noqa: E402
 import entry_driver as ed  # noqa: E402
 
 

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import blend_oracle as bo
-from oracle import stub_host as sh
+from hostsim import stub_host as sh
 
 pytestmark = pytest.mark.gpu
 

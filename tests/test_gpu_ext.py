@@ -8,7 +8,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import blend_oracle as bo
-from oracle import stub_host as sh
+from hostsim import stub_host as sh
 
 pytestmark = pytest.mark.gpu
 

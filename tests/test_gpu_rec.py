@@ -7,7 +7,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from oracle import ldm_decoder as ld
+from hostsim import ldm_decoder as ld
 from oracle import vae_oracle as vo
 
 pytestmark = pytest.mark.gpu
@@ -315,3 +315,28 @@ def test_live_windows_on_the_fp32_handover_kernels(plugin, cuda, mode):
         E.set_precision(E.PRECISION_BF16X3)
     assert torch.equal(outs[True], outs[False])
     assert 0 < px[True] < 0.92 * px[False], px
+
+
+@pytest.mark.parametrize("B,cin,cout,H,W,up,res", REC_CASES + [(3, 128, 256, 45, 77, False, True), (2, 512, 128, 30, 200, True, False), (1, 64, 128, 90, 130, False, True)])
+def test_two_blocks_per_cu_kernels_are_bit_identical_to_the_one_block_kernels(plugin, cuda, monkeypatch, B, cin, cout, H, W, up, res):
+    """csrc/vae_conv_rec2.hip (two independent 4-wave blocks per CU, default) issues every accumulator's MFMAs in the order of
+    csrc/vae_conv_rec.hip (one 8-wave block per CU, MDTILE_REC_BLOCKS=1): same fp32 output, same record image, bit for bit -- also
+    with many items per block (the ring of step chunks and the input stages run on across item boundaries) and with the start-up
+    skew off / by block index / by the per-CU arrival counter."""
+    E = plugin.engine
+    torch.manual_seed(cin + 3 * cout + H)
+    conv = torch.nn.Conv2d(cin, cout, 3, 1, 1)
+    hin, win = (H // 2, W // 2) if up else (H, W)
+    x = torch.randn(B, cin, hin, win)
+    out_coef = _coef(B, cout, 11).to(cuda)
+    pc = E.PackedConv(conv.weight.detach().to(cuda), conv.bias.detach().to(cuda))
+    xrec = E.rec_from_f32(x.to(cuda), None if up else _coef(B, cin, 5).to(cuda))
+    rr = torch.randn(B, cout, H, W).to(cuda) if res else None
+    monkeypatch.setenv("MDTILE_REC_BLOCKS", "1")
+    y1, r1 = pc.call_rec(xrec, residual=rr, upsample2x=up, want_f32=True, want_rec=True, rec_coef=out_coef)
+    for skew in ("2", "0", "1"):
+        monkeypatch.setenv("MDTILE_REC_BLOCKS", "2")
+        monkeypatch.setenv("MDTILE_REC2_SKEW", skew)
+        y2, r2 = pc.call_rec(xrec, residual=rr, upsample2x=up, want_f32=True, want_rec=True, rec_coef=out_coef)
+        assert torch.equal(y1, y2), f"fp32 output differs (skew mode {skew}): {_rel(y2, y1)}"
+        assert torch.equal(r1.data, r2.data), f"record output differs (skew mode {skew})"

@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from oracle import ldm_decoder as ld
+from hostsim import ldm_decoder as ld
 
 pytestmark = pytest.mark.gpu
 
@@ -63,7 +63,7 @@ def _worker(rank, world, port, H, W, q):
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        from oracle import stub_host as sh
+        from hostsim import stub_host as sh
         dev = torch.device("cuda:0")
         sh.install(dev)
         sh.set_device(dev)

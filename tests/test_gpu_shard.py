@@ -88,7 +88,7 @@ def test_vae_multi_device_sweep_matches_single_device(plugin, cuda):
     """VAEHook.devices: single-process multi-device decode (tiles dealt round-robin, per-device packed weights and streams, output
     rectangles copied to the first device).  Listing cuda:0 twice runs the whole flow on one GPU; the result must equal the ordinary
     sweep bit for bit (same kernels, same frozen statistics)."""
-    from oracle import ldm_decoder as ld
+    from hostsim import ldm_decoder as ld
     dec = ld.make_decoder(4).to(cuda)
     dec.original_forward = dec.forward
     torch.manual_seed(13)

@@ -7,8 +7,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from oracle import ldm_decoder as ld
-from oracle import stub_host as sh
+from hostsim import ldm_decoder as ld
+from hostsim import stub_host as sh
 from oracle import vae_oracle as vo
 
 pytestmark = pytest.mark.gpu

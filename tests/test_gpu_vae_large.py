@@ -13,7 +13,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from oracle import ldm_decoder as ld
+from hostsim import ldm_decoder as ld
 from oracle import vae_oracle as vo
 
 pytestmark = pytest.mark.gpu

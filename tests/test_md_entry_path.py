@@ -13,7 +13,7 @@ import pytest
 import torch
 
 import entry_driver as ed
-from oracle import stub_host as sh
+from hostsim import stub_host as sh
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "entry.npz")
 IDS = [c["name"] for c in ed.ENTRY_CASES]

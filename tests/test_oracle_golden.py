@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import blend_oracle as bo
-from oracle import ldm_decoder as ld
+from hostsim import ldm_decoder as ld
 from oracle import vae_oracle as vo
 
 

@@ -5,8 +5,8 @@ import pytest
 import torch
 
 from oracle import blend_oracle as bo
-from oracle import ldm_decoder as ld
-from oracle import stub_host as sh
+from hostsim import ldm_decoder as ld
+from hostsim import stub_host as sh
 from oracle import vae_oracle as vo
 
 pytestmark = pytest.mark.skipif(not sh.reference_available(), reason="/root/reference not mounted")

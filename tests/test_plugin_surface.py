@@ -3,7 +3,7 @@ import inspect
 
 import pytest
 
-from oracle import stub_host as sh
+from hostsim import stub_host as sh
 
 
 def test_script_titles_and_visibility(plugin):

@@ -82,7 +82,7 @@ def _free_port() -> int:
 
 
 def _program():
-    from oracle import ldm_decoder as ld, stub_host as sh
+    from hostsim import ldm_decoder as ld, stub_host as sh
     sh.install("cpu")
     pl = sh.load_plugin()
     dec = ld.make_decoder(4, small=True)
@@ -151,7 +151,8 @@ def test_unsplit_executor_matches_oracle_estimator():
     for p in (ROOT, PLUGIN):
         if p not in sys.path:
             sys.path.insert(0, p)
-    from oracle import ldm_decoder as ld, vae_oracle as vo
+    from hostsim import ldm_decoder as ld
+    from oracle import vae_oracle as vo
     steps = _program()
     torch.manual_seed(3)
     zs = torch.randn(1, 4, 12, 10)

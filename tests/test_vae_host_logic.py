@@ -19,7 +19,7 @@ for _p in (ROOT, PLUGIN, os.path.join(ROOT, "tests")):
 
 
 def _hook(net, ts, is_decoder, fast, color_fix=False):
-    from oracle import stub_host as sh
+    from hostsim import stub_host as sh
     import torch_engine as te
     sh.install("cpu")
     pl = sh.load_plugin()
@@ -31,7 +31,8 @@ def _hook(net, ts, is_decoder, fast, color_fix=False):
 
 @pytest.mark.parametrize("fast", [True, False])
 def test_decode_matches_oracle(fast):
-    from oracle import ldm_decoder as ld, vae_oracle as vo
+    from hostsim import ldm_decoder as ld
+    from oracle import vae_oracle as vo
     dec = ld.make_decoder(0, small=True)
     torch.manual_seed(2)
     z = torch.randn(1, 4, 36, 44)
@@ -44,7 +45,8 @@ def test_decode_matches_oracle(fast):
 
 @pytest.mark.parametrize("fast,color_fix", [(True, False), (False, False), (True, True)])
 def test_encode_matches_oracle(fast, color_fix):
-    from oracle import ldm_decoder as ld, vae_oracle as vo
+    from hostsim import ldm_decoder as ld
+    from oracle import vae_oracle as vo
     enc = ld.make_encoder(0, small=True)
     torch.manual_seed(4)
     x = torch.randn(1, 3, 136, 200)
@@ -69,7 +71,8 @@ def _worker(rank, world, port, fast, q, hw=(40, 56)):
         os.environ["MASTER_PORT"] = str(port)
         dist.init_process_group("gloo", rank=rank, world_size=world)
         torch.set_num_threads(1)
-        from oracle import ldm_decoder as ld, vae_oracle as vo
+        from hostsim import ldm_decoder as ld
+        from oracle import vae_oracle as vo
         dec = ld.make_decoder(0, small=True)
         torch.manual_seed(2)
         z = torch.randn(1, 4, *hw)
@@ -147,7 +150,7 @@ def _rec_hook(net, ts, fast=True, rec_convs=True):
 def test_live_windows_of_the_sd_decoder_program():
     """Grow = 1 / 3 / 6 latent px behind the 8x / 4x / 2x upsample convs (3 resblocks per level + conv_out), the 1x level whole; windows
     nest, are clamped to the tile and are given in input px of each upsample conv relative to its already narrowed input plane."""
-    from oracle import ldm_decoder as ld
+    from hostsim import ldm_decoder as ld
     hook = _rec_hook(ld.make_decoder(0, small=True), 16)
     pl = sys.modules[type(hook).__module__]
     steps = hook.program()
@@ -175,7 +178,8 @@ def test_live_windows_of_the_sd_decoder_program():
 @pytest.mark.parametrize("hw,ts,stacked_origins", [((36, 44), 16, False), ((70, 40), 16, True), ((64, 40), 24, False)])
 def test_fast_decode_with_live_windows_matches_oracle_and_the_whole_tile_sweep(hw, ts, stacked_origins, rec_convs):
     """The record-path sweep on torch doubles: narrowed tiles == whole padded tiles == the oracle; and the narrowing does shed work."""
-    from oracle import ldm_decoder as ld, vae_oracle as vo
+    from hostsim import ldm_decoder as ld
+    from oracle import vae_oracle as vo
     import torch_engine as te
     torch.manual_seed(5)
     z = torch.randn(1, 4, *hw)
@@ -209,7 +213,7 @@ def test_fast_decode_with_live_windows_matches_oracle_and_the_whole_tile_sweep(h
 def test_live_windows_are_exact_and_tight_in_float64():
     """One tile through the record sweep in float64 (rounding out of the picture): inside the valid rectangle the narrowed sweep equals
     the whole-tile sweep to float64 rounding, and windows one latent pixel smaller do NOT (the bound is the reach of the convs, not slack)."""
-    from oracle import ldm_decoder as ld
+    from hostsim import ldm_decoder as ld
     hook = _rec_hook(ld.make_decoder(3, small=True).double(), 16)
     pl = sys.modules[type(hook).__module__]
     steps = hook.program()

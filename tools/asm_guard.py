@@ -9,7 +9,8 @@ device assembly and checks the emitted instruction stream instead:
     * no `s_waitcnt` with a vmcnt between a DMA and its M0 restore, no other M0 writer inside the quintuple
     * every s_barrier is directly preceded (ignoring scalar ALU) by an s_waitcnt, and the vmcnt values those waits count are exactly
       the ones the source asks for: {0, 5} in k_conv3x3_rec (the 5 input pieces of the next K-step may stay in flight at dy = 1),
-      {0} in k_upconv_rec and k_attn_bf16x3 (lgkmcnt-only waits -- LDS hand-overs that consume no DMA -- are reported separately)
+      {0} in k_upconv_rec and k_attn_bf16x3 (lgkmcnt-only waits -- LDS hand-overs that consume no DMA -- are reported separately),
+      {0, 2, 3, 4} in k_conv3x3_rec2 and {0, 6, 7, 8, 9} in k_upconv_rec2 (one counted wait per step position, csrc/vae_conv_rec2.hip)
     * MFMA counts per unrolled trip match the source (conv: 36 half-steps x 12; upconv: 24 combo-steps x 12; attention: 24 / slab)
 usage: python tools/asm_guard.py   (exit code 0 = ok; prints one line per kernel)      -- also run by tests/test_host_abi.py
 """
@@ -23,12 +24,20 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CSRC = os.path.join(ROOT, "multidiffusion-upscaler-for-automatic1111_amd", "csrc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-pragma-unroll-threshold=262144", "-S", "--cuda-device-only"]
+EXT = os.path.join(ROOT, "multidiffusion-upscaler-for-automatic1111_amd")
+CSRC = os.path.join(EXT, "csrc")
+# the SAME compiler and code-generation flags as the build (mdtile/build.py), so that the stream checked here is the stream linked
+# into libmdtile.so; only the output kind differs (-S, device side only)
+sys.path.insert(0, EXT)
+from mdtile.build import HIPCC_FLAGS, hipcc_path  # noqa: E402
+
+FLAGS = [f for f in HIPCC_FLAGS if f not in ("-shared",)] + ["-S", "--cuda-device-only"]
 
 
 def device_asm(src: str) -> list:
-    hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"
+    hipcc = hipcc_path()
+    if hipcc is None:
+        raise RuntimeError("hipcc not found")
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "k.s")
         r = subprocess.run([hipcc] + FLAGS + [src, "-o", out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
@@ -78,7 +87,8 @@ def check_kernel(name: str, ins: list, expect: dict) -> list:
         # walk back over scalar ALU and branches: a wait selected by a (wave-uniform) branch sits in its own basic block in front of
         # the barrier's block, e.g.  s_waitcnt vmcnt(0) / loop header / s_cbranch / s_waitcnt vmcnt(5) / s_barrier
         j, found = k - 1, []
-        while j >= 0 and (re.match(r"s_(mov|add|and|or|lshl|lshr|mul|cmp|cselect|sub|ashr|bfe|nop|xor|not|max|min|addc|bitcmp|cbranch|branch|waitcnt)", ins[j])):
+        # (v_readlane / v_writelane: SGPR spill traffic of the scalar address arithmetic -- register moves, no memory)
+        while j >= 0 and (re.match(r"s_(mov|add|and|or|lshl|lshr|mul|cmp|cselect|sub|ashr|bfe|nop|xor|not|max|min|addc|bitcmp|cbranch|branch|waitcnt)|v_readlane_b32|v_writelane_b32", ins[j])):
             if ins[j].startswith("s_waitcnt"):
                 found.append(ins[j])
             j -= 1
@@ -105,6 +115,7 @@ def check_kernel(name: str, ins: list, expect: dict) -> list:
 def main() -> int:
     errs = []
     rec = kernels(device_asm(os.path.join(CSRC, "vae_conv_rec.hip")))
+    rec2 = kernels(device_asm(os.path.join(CSRC, "vae_conv_rec2.hip")))
     att = kernels(device_asm(os.path.join(CSRC, "vae_attn_bf16x3.hip")))
     c11 = kernels(device_asm(os.path.join(CSRC, "vae_conv1x1_bf16x3.hip")))
     plan = [
@@ -112,7 +123,10 @@ def main() -> int:
         (c11, "k_conv1x1_streamILi4", dict(dma_min=4, barrier_vmcnt=[0, 4], mfma_multiple=24)),
         (rec, "k_conv3x3_recILi2ELi2ELi4", dict(dma_min=8, barrier_vmcnt=[0, 5], mfma_multiple=12)),
         (rec, "k_conv3x3_recILi1ELi1ELi2", dict(dma_min=4, barrier_vmcnt=[0, 5], mfma_multiple=3)),
-        (rec, "k_upconv_rec", dict(dma_min=8, barrier_vmcnt=[0], mfma_multiple=12)),
+        (rec, "k_upconv_recE", dict(dma_min=8, barrier_vmcnt=[0], mfma_multiple=12)),
+        # two blocks per CU: one counted wait per step position (tools/rec2_protocol_sim.py derives and checks the values)
+        (rec2, "k_conv3x3_rec2ILi2ELi2ELi4", dict(dma_min=8, barrier_vmcnt=[0, 2, 3, 4], mfma_multiple=12)),
+        (rec2, "k_upconv_rec2E", dict(dma_min=8, barrier_vmcnt=[0, 6, 7, 8, 9], mfma_multiple=12)),
         (att, "k_attn_bf16x3ILi512", dict(dma_min=8, barrier_vmcnt=[0], mfma_multiple=6)),
         (att, "k_attn_bf16x3ILi256", dict(dma_min=8, barrier_vmcnt=[0], mfma_multiple=6)),
         (att, "k_attn_bf16x3ILi128", dict(dma_min=8, barrier_vmcnt=[0], mfma_multiple=6)),
