@@ -572,10 +572,24 @@ static int num_cus() {
 // vae_conv_rec2.hip: the two-blocks-per-CU form of the cout % 128 == 0 kernels
 int conv_rec2_launch(ConvRParams P, int B, int up, hipStream_t s, int cus);
 
-// MDTILE_REC_BLOCKS=1: the one-block-per-CU kernels of this file for every shape (A/B against vae_conv_rec2.hip; read per launch)
-static bool rec_two_blocks() {
-    const char* e = getenv("MDTILE_REC_BLOCKS");
-    return !(e && e[0] == '1');
+// Which kernel family takes a launch.  The two-blocks-per-CU kernels (vae_conv_rec2.hip) lose 3-12 % on launches that fill the chip many
+// times over (profiles/r4a: their 8-row items double the weight stream through the CU's memory pipe and the store epilogue is not
+// hidden), but their items are half as large and 512 of them are resident: launches of only a few item rounds quantise better
+// (512 -> 512 at 86 x 86 x 3 tiles: +56 %, at 278 x 278: +2 ... +12 %; at 256 x 256, an exact fit of the one-block grid: -5 %).
+// Cost model, in units of one 16-row item on a CU of its own (fitted on profiles/r4d/conv_two_blocks_small_launches.log):
+//   one block / CU:   ceil(items16 / CUs)
+//   two blocks / CU:  full rounds of 2 CUs items cost `pair`; a last round of <= CUs items (each block alone on its CU) costs `lone`
+// MDTILE_REC_BLOCKS=1 / 2 forces a family (A/B in probes/conv_rec2_ab.py; read per launch).
+static bool rec_two_blocks(long long items16, long long items8, int cus, int up) {
+    if (const char* e = getenv("MDTILE_REC_BLOCKS")) {
+        if (e[0] == '1') return false;
+        if (e[0] == '2') return true;
+    }
+    const double pair = up ? 1.13 : 1.05, lone = up ? 0.62 : 0.60;
+    const double t1 = (double)((items16 + cus - 1) / cus);
+    const long long full = items8 / (2 * cus), rem = items8 - full * 2 * cus;
+    const double t2 = full * pair + (rem == 0 ? 0.0 : rem <= cus ? lone : pair);
+    return t2 < 0.97 * t1;
 }
 
 bool conv_rec_supported(int cout, int cin, int ksize) { return ksize == 3 && cin % 32 == 0 && (cout % 128 == 0 || (cout >= 1 && cout < 32)); }
@@ -616,7 +630,14 @@ int conv_rec_launch(const void* d_xrec, const void* d_w_rec, const float* d_bias
     P.dbg = 0;
     if (const char* e = getenv("MDTILE_REC_DBG")) P.dbg = atoi(e);      // probing only (probes/conv_rec2_ab.py): see ConvRParams::dbg
     if (up) P.w = (const u32x4*)d_w_rec + conv_bf16x3_direct_records(cout, cin);
-    if (cout % 128 == 0 && rec_persistent() && rec_two_blocks()) return conv_rec2_launch(P, B, up, s, num_cus());
+    if (cout % 128 == 0 && rec_persistent()) {
+        const int cus = num_cus() / 8 * 8;
+        const int hin = up ? P.Hin : H, win = up ? P.Win : W, per = P.NCB * (up ? 2 : 1);      // items tile the INPUT grid of the sub-pixel form
+        const long long px = (win + 31) / 32;
+        const long long items16 = (px * ((hin + (up ? 7 : 15)) / (up ? 8 : 16)) + 7) / 8 * 8 * per * B;
+        const long long items8 = (px * ((hin + (up ? 3 : 7)) / (up ? 4 : 8)) + 7) / 8 * 8 * per * B;
+        if (rec_two_blocks(items16, items8, cus, up)) return conv_rec2_launch(P, B, up, s, num_cus());
+    }
     if (up) {
         P.PX = (P.Win + 31) / 32;
         P.ptiles = P.PX * ((P.Hin + 7) / 8);

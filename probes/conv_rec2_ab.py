@@ -21,6 +21,12 @@ SHAPES = [  # cin, cout, H, W (output), upsample
     (512, 512, 556, 556, True),
     (512, 256, 1112, 1112, False),
     (256, 128, 2224, 2224, False),
+    (512, 512, 278, 278, False, 2),      # 9 .. 12: the 1x level of a decoder tile, stacked 2 / 3 deep (TILE_BATCH), and its un-padded form
+    (512, 512, 278, 278, False, 3),
+    (512, 512, 256, 256, False),
+    (512, 512, 556, 556, True, 3),
+    (512, 512, 139, 139, False),         # 13: half-size tile (decoder tile 128)
+    (512, 512, 86, 86, False, 3),        # 14: decoder tile 64, three tiles
 ]
 if "--shapes" in sys.argv:
     SHAPES = [SHAPES[int(i)] for i in sys.argv[sys.argv.index("--shapes") + 1].split(",")]
@@ -72,28 +78,30 @@ def census(fn, grid=512):
 
 
 torch.manual_seed(0)
-for cin, cout, H, W, up in SHAPES:
+for shape in SHAPES:
+    cin, cout, H, W, up = shape[:5]
+    B = shape[5] if len(shape) > 5 else 1
     conv = torch.nn.Conv2d(cin, cout, 3, 1, 1).to(dev)
     if ZEROS:
         with torch.no_grad():
             conv.weight.zero_()
     pc = E.PackedConv(conv.weight.detach(), conv.bias.detach())
     hin, win = (H // 2, W // 2) if up else (H, W)
-    x = torch.randn(1, cin, hin, win, device=dev)
+    x = torch.randn(B, cin, hin, win, device=dev)
     if ZEROS:
         x.zero_()
-    res = None if up else torch.randn(1, cout, H, W, device=dev)
-    coef_in = torch.stack([torch.rand(1, cin, device=dev) + 0.5, torch.randn(1, cin, device=dev) * 0.3], dim=1).contiguous()
-    coef_out = torch.stack([torch.rand(1, cout, device=dev) + 0.5, torch.randn(1, cout, device=dev) * 0.3], dim=1).contiguous()
+    res = None if up else torch.randn(B, cout, H, W, device=dev)
+    coef_in = torch.stack([torch.rand(B, cin, device=dev) + 0.5, torch.randn(B, cin, device=dev) * 0.3], dim=1).contiguous()
+    coef_out = torch.stack([torch.rand(B, cout, device=dev) + 0.5, torch.randn(B, cout, device=dev) * 0.3], dim=1).contiguous()
     if ZEROS:
         coef_in.zero_()
     xrec = E.rec_from_f32(x, None if up else coef_in)
-    flops = 2.0 * H * W * cout * cin * (4 if up else 9)        # EXECUTED flops (the sub-pixel form runs 4 taps)
+    flops = 2.0 * B * H * W * cout * cin * (4 if up else 9)        # EXECUTED flops (the sub-pixel form runs 4 taps)
     forms = {
         "rec->rec ": lambda: pc.call_rec(xrec, upsample2x=up, want_f32=False, want_rec=True, rec_coef=coef_out),
         "rec->both": lambda: pc.call_rec(xrec, residual=res, upsample2x=up, want_f32=True, want_rec=True, rec_coef=coef_out),
     }
-    print(f"{cin:4d}->{cout:4d} {H}x{W}{' up' if up else '   '}", flush=True)
+    print(f"{cin:4d}->{cout:4d} {H}x{W}{' up' if up else '   '} B={B}", flush=True)
     for name, fn in forms.items():
         setenv(MDTILE_REC_BLOCKS=1)
         y1, r1 = fn()
