@@ -533,6 +533,37 @@ def main():
                                       "engine (default precision) vs oracle/vae_oracle.py run on this GPU via torch fp32 conv / bmm (oracle/gpu_reference.py), "
                                       f"{t_oracle:.0f} s; the tile shapes are the four of the 8K decode; also tests/test_gpu_vae_large.py"})
         del ref, out
+        # ---- the BENCHMARKED image itself against the oracle: single tiles of the 8K decode.  With every GroupNorm frozen by the
+        # estimator (fast mode) a tile's pixels depend on no other tile, so the oracle can decode any one of upstream's 16 tiles of the 8K
+        # latent alone (oracle/vae_oracle.py: only_tiles; the restriction equals the full sweep bit for bit, tests/test_oracle_golden.py)
+        # with the statistics of its own estimator pass over the same latent.  Checked: an INTERIOR tile (278 x 278 latent px, padded on
+        # all four sides -- the class the live-window narrowing changes most), a right-edge tile and the bottom-right corner tile.
+        if L == 1024 and not args.slow_vae:
+            from oracle import vae_oracle as vo8
+            ins8, _ = vo8.split_tiles(L, L, args.vae_tile)
+            cols = int(round(len(ins8) ** 0.5))
+            picks = {"interior": cols + 1, "right_edge": 2 * cols - 1, "corner": len(ins8) - 1}
+            builtins.print = lambda *a, **k: None
+            try:
+                img8 = hook(z).float()
+                t0 = time.perf_counter()
+                crops = gr.tiled_forward_gpu(dec, z, args.vae_tile, fast=True, only_tiles=list(picks.values()))
+                t_or8 = time.perf_counter() - t0
+            finally:
+                builtins.print = _print
+            den8 = img8.abs().max().item()
+            per_tile = {}
+            for (name, t), (ob, crop) in zip(picks.items(), crops):
+                mine = img8[:, :, ob[2]:ob[3], ob[0]:ob[1]]
+                d = (mine - crop.to(mine.device)).abs()
+                per_tile[name] = {"tile": t, "latent_in_bbox": ins8[t], "image_out_bbox": ob, "rel_err": float(d.max().item() / den8),
+                                  "rms_err": float((d.pow(2).mean().sqrt() / den8).item())}
+            parity.update({"rel_err_vs_oracle_8k_interior": per_tile["interior"]["rel_err"],
+                           "rel_err_vs_oracle_8k_tiles": per_tile,
+                           "oracle_8k_what": f"tiles of the TIMED 8192x8192 image (live windows {'on' if pl.tilevae.LIVE_WINDOW else 'off'}) against the oracle's decode of the same "
+                                             f"tiles of the same latent with its own estimator statistics (torch fp32 on this GPU, {t_or8:.0f} s); "
+                                             "errors relative to the image's absolute maximum"})
+            del img8, crops
 
     # ------------------------------------------------------------------ CPU baseline (oracle = port of the reference), rank 0, N=1
     cpu_baseline = None

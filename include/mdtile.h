@@ -325,6 +325,9 @@ int mdtile_gn_from_sums(const double* d_sums, double count, int BG, float* d_mea
 #define MDTILE_ATTN_EXACT_F32 1
 #define MDTILE_ATTN_V_CHANNEL_MAJOR 2   /* v is [B,C,T] like q and k (split-bf16 kernel only): the v projection then runs on the same 1x1 kernels */
 size_t mdtile_vae_attn_ws_size(int B, int C, int T);
+/* 1 when mdtile_vae_attn(C, flags) will run the split-bf16 kernel and therefore accepts MDTILE_ATTN_V_CHANNEL_MAJOR -- the SAME conditions
+ * the dispatch inside mdtile_vae_attn tests (flags, mdtile_set_precision, env MDTILE_ATTN_MODE=f32, C); 0: hand v over token-major. */
+int mdtile_vae_attn_takes_channel_major(int C, int flags);
 int mdtile_vae_attn(const float* d_q, const float* d_k, const float* d_v, float* d_out, int B, int C, int T, float scale,
                     int flags, void* d_ws, mdtile_stream_t stream);
 /* Same contraction with separate query / key token counts: q [B,C,Tq], k [B,C,Tk], v [B,Tk,C] -> out [B,C,Tq]

@@ -222,13 +222,19 @@ extern "C" size_t mdtile_vae_attn_ws_size(int B, int C, int T) {
     return attn_bf16x3_ws_bytes(B, C, T, T);
 }
 
+// one predicate for the dispatch below AND for the host's choice of the v layout (round 3's host-side test looked at mdtile_get_precision,
+// which reports F32 only when conv AND attention are forced: MDTILE_ATTN_MODE=f32 alone sent a channel-major v to the exact kernel)
+static bool attn_takes_bf16x3(int C, int flags) { return !(flags & MDTILE_ATTN_EXACT_F32) && !attn_force_f32() && attn_bf16x3_eligible(C); }
+
+extern "C" int mdtile_vae_attn_takes_channel_major(int C, int flags) { return attn_takes_bf16x3(C, flags) ? 1 : 0; }
+
 extern "C" int mdtile_vae_attn(const float* d_q, const float* d_k, const float* d_v, float* d_out, int B, int C, int T, float scale,
                                int flags, void* d_ws, mdtile_stream_t stream) {
     MDT_CHECK_ARG(d_q && d_k && d_v && d_out, "mdtile_vae_attn: null argument");
     MDT_CHECK_ARG(B > 0 && B <= 65535 && T > 0, "mdtile_vae_attn: bad shape B=%d T=%d", B, T);
     MDT_CHECK_ARG(C == 128 || C == 256 || C == 512, "mdtile_vae_attn: C=%d unsupported (128, 256 or 512)", C);
     hipStream_t s = as_stream(stream);
-    if (!(flags & MDTILE_ATTN_EXACT_F32) && !attn_force_f32() && attn_bf16x3_eligible(C)) {
+    if (attn_takes_bf16x3(C, flags)) {
         MDT_CHECK_ARG(d_ws, "mdtile_vae_attn: the split-bf16 path needs the workspace of mdtile_vae_attn_ws_size()");
         return attn_bf16x3_launch(d_q, d_k, d_v, d_out, B, C, T, T, scale, d_ws, s, (flags & MDTILE_ATTN_V_CHANNEL_MAJOR) != 0);
     }

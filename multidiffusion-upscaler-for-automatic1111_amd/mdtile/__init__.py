@@ -127,6 +127,7 @@ _SIGNATURES = {
     "mdtile_upconv2d_rec_window": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_int, c_int,
                                                                                                                   c_void_p]),
     "mdtile_vae_attn_ws_size": (c_size_t, [c_int, c_int, c_int]),
+    "mdtile_vae_attn_takes_channel_major": (c_int, [c_int, c_int]),
     "mdtile_vae_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p]),
     "mdtile_crop_store": (c_int, [c_void_p, c_int, c_int, c_int, c_int, _IP, _IP, c_int, c_void_p, c_int, c_int, c_void_p]),
     "mdtile_vae_fast_size": (c_int, [c_int, c_int, c_int, _IP, _IP]),
@@ -828,9 +829,10 @@ def vae_attn(q: torch.Tensor, k: torch.Tensor, v_tok: torch.Tensor, scale: float
     return out
 
 
-def v_channel_major_ok() -> bool:
-    """True when vae_attn takes a channel-major v (the split-bf16 kernel; the exact-fp32 kernel wants it token-major)."""
-    return get_precision() == PRECISION_BF16X3
+def v_channel_major_ok(C: int = 512, exact: bool = False) -> bool:
+    """True when vae_attn(C channels) takes a channel-major v (the split-bf16 kernel; the exact-fp32 kernel wants it token-major).
+    Asked of the library: the answer uses the very predicate mdtile_vae_attn dispatches on (precision mode, MDTILE_ATTN_MODE, C)."""
+    return bool(lib().mdtile_vae_attn_takes_channel_major(int(C), ATTN_EXACT_F32 if exact else 0))
 
 
 def vae_attn_qk(q: torch.Tensor, k: torch.Tensor, v_tok: torch.Tensor, scale: float) -> torch.Tensor:

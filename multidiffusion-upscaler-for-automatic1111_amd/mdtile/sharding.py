@@ -20,7 +20,7 @@ VAE decode: tiles are dealt round-robin; the fast-mode statistics estimator (one
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import List, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -315,6 +315,8 @@ def init_process_context_checked(rank: int, world: int, device: int, timeout_s: 
     global _CTX
     import sys
     import mdtile
+    _CTX = None          # the reference exchange of step 3 must take the torch.distributed path, whatever an earlier call left installed
+    check_scratch: dict = {}      # private to this bring-up (see exchange_and_sum_ctx)
     dev = torch.device("cuda", device) if torch.cuda.is_available() else torch.device("cpu")   # (cpu: the gloo tests of this logic)
     box = [None]
     if rank == 0:
@@ -339,7 +341,7 @@ def init_process_context_checked(rank: int, world: int, device: int, timeout_s: 
         def _check():
             ctx.selfcheck()
             a = _payload()
-            exchange_and_sum_ctx(a, bands, ctx)
+            exchange_and_sum_ctx(a, bands, ctx, scratch=check_scratch)
             if dev.type == "cuda":
                 torch.cuda.synchronize(dev)
             return a
@@ -374,15 +376,18 @@ def band_rows_table(bands: Sequence[Band]) -> List[int]:
     return out
 
 
-def exchange_and_sum_ctx(partial: torch.Tensor, bands: Sequence[Band], ctx=None) -> torch.Tensor:
-    """exchange_and_sum on a shard context holding ONE local rank (this process): in place, on torch's current stream."""
+def exchange_and_sum_ctx(partial: torch.Tensor, bands: Sequence[Band], ctx=None, scratch: Optional[dict] = None) -> torch.Tensor:
+    """exchange_and_sum on a shard context holding ONE local rank (this process): in place, on torch's current stream.
+    scratch: the cache of halo scratch buffers to use (default: the module's, which belongs to the installed context -- the bring-up
+    check passes its own, so that a worker thread abandoned after a timeout can never touch the one the job goes on to use)."""
     ctx = ctx or _CTX
+    cache = _CTX_SCRATCH if scratch is None else scratch
     table = band_rows_table(bands)
     key = (tuple(table), tuple(partial.shape), partial.device.index)
-    if key not in _CTX_SCRATCH:
-        _CTX_SCRATCH.clear()
-        _CTX_SCRATCH[key] = ctx.halo_scratch(table, partial.shape[0], partial.shape[1], partial.shape[3])
-    ctx.halo_exchange([partial], _CTX_SCRATCH[key], table, streams=[torch.cuda.current_stream(partial.device).cuda_stream])
+    if key not in cache:
+        cache.clear()
+        cache[key] = ctx.halo_scratch(table, partial.shape[0], partial.shape[1], partial.shape[3])
+    ctx.halo_exchange([partial], cache[key], table, streams=[torch.cuda.current_stream(partial.device).cuda_stream])
     return partial
 
 

@@ -82,7 +82,7 @@ class AttnPack:
         q = self.q(h).view(B, C, H * W)
         k = self.k(h).view(B, C, H * W)
         scale = float(int(C) ** (-0.5))
-        if getattr(self.engine, "v_channel_major_ok", lambda: False)():
+        if getattr(self.engine, "v_channel_major_ok", lambda c: False)(C):
             # v like q and k: channel-major through the split-bf16 1x1 kernel; the attention prep reads it in that layout
             o = self.engine.vae_attn(q, k, self.v(h).view(B, C, H * W), scale, v_channel_major=True)
         else:
@@ -344,7 +344,14 @@ class VAEHook:
         px = h * w * (64 if self.is_decoder else 1)
         per_tile = 5 * 4 * 128 * px * N
         free, _total = torch.cuda.mem_get_info(dev)
-        return max(1, min(TILE_BATCH, int(0.6 * free // max(per_tile, 1))))
+        # blocks torch's caching allocator holds but has handed to nobody are as good as free for the next sweep (after the first decode,
+        # or a UNet run, the driver-level figure alone can be tiny on cards smaller than the 288 GB this was developed on)
+        free += max(0, torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev))
+        tb = max(1, min(TILE_BATCH, int(0.6 * free // max(per_tile, 1))))
+        if tb < TILE_BATCH and not getattr(self, "_said_tb", False):
+            self._said_tb = True
+            print(f"[Tiled VAE]: {tb} instead of {TILE_BATCH} tiles per sweep ({free / 2**30:.1f} GiB free, {per_tile / 2**30:.1f} GiB per {h}x{w} tile)")
+        return tb
 
     # ---- fast mode, every norm frozen: record-image hand-over between the 3x3 convs ----------------------------------
     @staticmethod
@@ -794,7 +801,18 @@ class VAEHook:
                     self._apply_norm(steps, tiles[i], *pooled)
                 forward = not forward
 
-        if nan_flags and bool(torch.stack(nan_flags).any().item()):
+        nan_seen = bool(nan_flags) and bool(torch.stack(nan_flags).any().item())
+        if world > 1 and self.gather_to is not None:
+            # The gather below is a grouped exchange EVERY rank must enter (or none): a rank that was interrupted, or whose NaN check
+            # raises, would leave the others -- and the root's receives -- waiting for ever.  So the ranks first agree on both flags (one
+            # small all-reduce), then skip the gather together / raise together.  Upstream tests every tile of the image it returns
+            # (tilevae.py:633-634): with the flags summed the root sees a NaN found on any rank.
+            from mdtile import sharding
+            agree = torch.tensor([1.0 if interrupted else 0.0, 1.0 if nan_seen else 0.0], dtype=torch.float32, device=dev)
+            sharding.comm_allreduce_sum(agree)
+            flags = agree.tolist()
+            interrupted, nan_seen = flags[0] > 0.0, flags[1] > 0.0
+        if nan_seen:
             devices.test_for_nans(torch.full((1,), float("nan")), "vae")     # raises the host's NansException (or not: --disable-nan-check)
         if world > 1 and self.gather_to is not None and not interrupted:
             from mdtile import sharding

@@ -68,8 +68,9 @@ def reference_arithmetic(chunked_attention: bool = True):
 
 
 @torch.no_grad()
-def tiled_forward_gpu(net, z: torch.Tensor, tile_size: int, fast: bool, is_decoder: bool = True, color_fix: bool = False) -> torch.Tensor:
-    """vo.tiled_forward (upstream vae_tile_forward, scripts/tilevae.py:507-656) on the device `net` lives on."""
+def tiled_forward_gpu(net, z: torch.Tensor, tile_size: int, fast: bool, is_decoder: bool = True, color_fix: bool = False, only_tiles=None):
+    """vo.tiled_forward (upstream vae_tile_forward, scripts/tilevae.py:507-656) on the device `net` lives on.
+    only_tiles: see vo.tiled_forward -- [(out_bbox, cropped tile), ...] of the listed tiles (fast mode)."""
     dev = next(net.parameters()).device
     with reference_arithmetic():
-        return vo.tiled_forward(net, z.to(dev), tile_size, fast, is_decoder=is_decoder, color_fix=color_fix)
+        return vo.tiled_forward(net, z.to(dev), tile_size, fast, is_decoder=is_decoder, color_fix=color_fix, only_tiles=only_tiles)

@@ -206,16 +206,25 @@ def estimate_stats(ops, z_small: torch.Tensor, color_fix: bool = False) -> List[
 
 
 @torch.no_grad()
-def tiled_forward(net, z: torch.Tensor, tile_size: int, fast: bool, is_decoder: bool = True, color_fix: bool = False) -> torch.Tensor:
-    """tilevae.py:375-388 + 507-656.  Returns fp32 [N, C_out, 8H, 8W] (decoder)."""
+def tiled_forward(net, z: torch.Tensor, tile_size: int, fast: bool, is_decoder: bool = True, color_fix: bool = False,
+                  only_tiles: Optional[Sequence[int]] = None):
+    """tilevae.py:375-388 + 507-656.  Returns fp32 [N, C_out, 8H, 8W] (decoder).
+    only_tiles (fast mode with EVERY norm frozen only): decode just these tiles of upstream's split (indices into split_tiles' list) and
+    return [(out_bbox, cropped tile), ...] instead of the assembled image.  With all statistics frozen by the estimator
+    (tilevae.py:464-505, 586-589) a tile's result does not depend on any other tile, so this is exactly what the full sweep writes into
+    those rectangles -- the way to check single tiles of an image too large to decode whole on the checker (8K: 16 tiles)."""
     pad = DEC_PAD if is_decoder else ENC_PAD
     N, _, H, W = z.shape
     if max(H, W) <= pad * 2 + tile_size:                                   # tilevae.py:381-384
+        assert only_tiles is None
         return net(z)
     ins, outs = split_tiles(H, W, tile_size, is_decoder)
-    tiles = [z[:, :, b[2]:b[3], b[0]:b[1]].clone() for b in ins]
     ops = build_ops(net, is_decoder)
     frozen = estimate_stats(ops, fast_mode_input(z, tile_size), color_fix and not is_decoder) if fast else None
+    if only_tiles is not None:
+        assert frozen is not None and len(frozen) == sum(1 for k, _ in ops if k == "norm"), "only_tiles needs every GroupNorm frozen (fast mode)"
+        ins, outs = [ins[t] for t in only_tiles], [outs[t] for t in only_tiles]
+    tiles = [z[:, :, b[2]:b[3], b[0]:b[1]].clone() for b in ins]
     T = len(tiles)
     pos = [0] * T
     res = [[] for _ in range(T)]
@@ -245,6 +254,8 @@ def tiled_forward(net, z: torch.Tensor, tile_size: int, fast: bool, is_decoder: 
         norm_idx += 1
         if not is_frozen:                # a frozen norm is an inline task upstream: the sweep (and its direction) goes on
             forward = not forward
+    if only_tiles is not None:
+        return [(outs[t], crop_valid_region(tiles[t], ins[t], outs[t], is_decoder)) for t in range(T)]
     for t in range(T):
         tile = tiles[t]
         if result is None:                                                  # tilevae.py:629-632

@@ -303,8 +303,10 @@ def test_untiled_small_input_takes_original_forward(plugin, cuda):
 # encoder direction: stride-2 Downsample conv, encoder queue, pad 32, color_fix semi-fast mode
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,cin,cout,H,W", [(1, 128, 128, 40, 66), (2, 32, 32, 17, 21), (1, 256, 256, 64, 64), (1, 512, 512, 33, 95)])
-def test_downsample_conv_vs_torch(plugin, cuda, B, cin, cout, H, W):
-    """ldm Downsample: F.pad(x, (0,1,0,1)) then conv3x3 stride 2 (odd and even sizes)."""
+def test_downsample_conv_default_precision_vs_torch(plugin, cuda, B, cin, cout, H, W):
+    """ldm Downsample: F.pad(x, (0,1,0,1)) then conv3x3 stride 2 (odd and even sizes), default precision = the split-bf16 stride-2 kernel
+    (5e-5: one conv of split-bf16 operands).  (Until round 4 this test shared its name with the precision-parametrised one further down
+    and was silently replaced by it: tests/test_no_shadowed_tests.py now rejects duplicate test names.)"""
     E = plugin.engine
     torch.manual_seed(cin + H)
     conv = torch.nn.Conv2d(cin, cout, 3, 2, 0)
@@ -314,7 +316,7 @@ def test_downsample_conv_vs_torch(plugin, cuda, B, cin, cout, H, W):
     pc = E.PackedConv(conv.weight.detach().to(cuda), conv.bias.detach().to(cuda))
     out = pc.down2(x.to(cuda)).cpu()
     assert out.shape == ref.shape
-    assert _rel(out, ref) < 2e-5
+    assert _rel(out, ref) < 5e-5
 
 
 def test_tiled_encode_vs_goldens_and_oracle(plugin, cuda):
@@ -452,3 +454,31 @@ def test_attention_channel_major_v_equals_token_major(plugin, cuda, B, C, T):
     a = E.vae_attn(q, k, v.permute(0, 2, 1).contiguous(), scale)
     b = E.vae_attn(q, k, v, scale, v_channel_major=True)
     assert torch.equal(a, b)
+
+
+def test_attention_forced_to_exact_fp32_by_env_alone(cuda):
+    """env MDTILE_ATTN_MODE=f32 on its own (conv path untouched) -- documented in include/mdtile.h.  Round 3 regressed it: the host chose
+    the v layout from mdtile_get_precision(), which still said BF16X3, and the exact kernel rejected the channel-major v.  The choice is
+    now the library's own dispatch predicate (mdtile_vae_attn_takes_channel_major).  The switch is read when the library loads, so
+    the decode runs in a child process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from hostsim import stub_host as sh, ldm_decoder as ld\n"
+        "from oracle import vae_oracle as vo\n"
+        "sh.install('cuda:0'); sh.set_device('cuda:0'); pl = sh.load_plugin(); E = pl.engine\n"
+        "assert E.get_precision() == E.PRECISION_BF16X3 and not E.v_channel_major_ok(128) and not E.v_channel_major_ok(512)\n"
+        "dec = ld.make_decoder(2, small=True); torch.manual_seed(4); z = torch.randn(1, 4, 40, 36)\n"
+        "ref = vo.tiled_forward(dec, z, 16, True)\n"
+        "g = ld.make_decoder(2, small=True).to('cuda:0'); g.original_forward = g.forward\n"
+        "out = pl.tilevae.VAEHook(g, 16, is_decoder=True, fast_decoder=True, fast_encoder=False, color_fix=False)(z.to('cuda:0')).cpu()\n"
+        "err = (out - ref).abs().max().item() / ref.abs().max().item()\n"
+        "assert err < 2e-4, err\n"
+        "print('attn-f32-env ok', err)\n")
+    env = dict(os.environ, MDTILE_ATTN_MODE="f32")
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "attn-f32-env ok" in r.stdout, r.stdout[-3000:]

@@ -189,3 +189,33 @@ def test_assembled_cfg3_decode_vs_oracle_on_gpu(plugin, cuda):
         print(f"assembled cfg3 decode (fast={fast}): rel err vs the oracle {err:.2e}")
         assert err < 2e-4, f"assembled cfg3 decode (fast={fast}): rel err {err}"
         del ref, out
+
+
+@pytest.mark.parametrize("live", [True, False], ids=["live_windows", "whole_tiles"])
+def test_interior_tile_padded_on_four_sides_vs_oracle_on_gpu(plugin, cuda, live):
+    """Full-width SD decoder, 214 x 214 latent at decoder tile 64 -> 3 x 3 tiles; the CENTRE tile is padded by 11 latent px on all four
+    sides (86 x 86 in, 64 x 64 valid), the class of tile the live-window narrowing changes most (9 of the 16 tiles of the 8K decode)
+    and the one the 2 x 2 configurations (every tile on two image edges) never contain.  Assembled image vs the oracle on the GPU,
+    with the narrowing on and off; the centre tile's rectangle is also checked on its own."""
+    torch.manual_seed(37)
+    z = torch.randn(1, 4, 214, 214)
+    ins, outs = vo.split_tiles(214, 214, 64)
+    assert len(ins) == 9 and ins[4] == [64, 150, 64, 150] and outs[4] == [75 * 8, 139 * 8, 75 * 8, 139 * 8]
+    dec = ld.make_decoder(5).to(cuda)
+    dec.original_forward = dec.forward
+    ref = gr.tiled_forward_gpu(dec, z, 64, True).cpu()
+    torch.cuda.empty_cache()
+    hook = plugin.tilevae.VAEHook(dec, 64, is_decoder=True, fast_decoder=True, fast_encoder=False, color_fix=False)
+    old = plugin.tilevae.LIVE_WINDOW
+    try:
+        plugin.tilevae.LIVE_WINDOW = live
+        out = hook(z.to(cuda)).cpu()
+    finally:
+        plugin.tilevae.LIVE_WINDOW = old
+    assert out.shape == ref.shape == (1, 3, 1712, 1712)
+    err = _rel(out, ref)
+    ob = outs[4]
+    den = ref.abs().max().item()
+    err_centre = (out[:, :, ob[2]:ob[3], ob[0]:ob[1]] - ref[:, :, ob[2]:ob[3], ob[0]:ob[1]]).abs().max().item() / den
+    print(f"3 x 3 tiles at decoder tile 64 (live windows {live}): assembled rel err {err:.2e}, centre tile {err_centre:.2e}")
+    assert err < 2e-4 and err_centre < 2e-4, f"live={live}: assembled {err}, centre tile {err_centre}"

@@ -92,3 +92,22 @@ def test_gn_attn(golden_vae):
     hx = torch.randn(1, 64, 7, 9)
     with torch.no_grad():
         assert np.array_equal(vo.attn_body(ab, hx).numpy(), golden_vae["attn/out"])
+
+
+def test_only_tiles_is_the_full_sweep_restricted_to_those_tiles():
+    """oracle/vae_oracle.py: tiled_forward(only_tiles=...) -- fast mode, every GroupNorm frozen -- returns exactly the rectangles the full
+    sweep (pinned to upstream above and in tests/test_oracle_vs_reference.py) writes for those tiles: bench.py uses it to check single
+    tiles of the 8K image, which the checker cannot decode whole."""
+    from oracle import vae_oracle as vo
+    dec = ld.make_decoder(3, small=True)
+    torch.manual_seed(1)
+    z = torch.randn(1, 4, 70, 58)
+    full = vo.tiled_forward(dec, z, 16, True)
+    ins, outs = vo.split_tiles(70, 58, 16)
+    sel = [0, 4, len(ins) // 2, len(ins) - 1]
+    got = vo.tiled_forward(dec, z, 16, True, only_tiles=sel)
+    assert [ob for ob, _ in got] == [outs[t] for t in sel]
+    for ob, crop in got:
+        assert torch.equal(full[:, :, ob[2]:ob[3], ob[0]:ob[1]], crop)
+    with pytest.raises(AssertionError):
+        vo.tiled_forward(dec, z, 16, False, only_tiles=sel)      # slow mode pools statistics over ALL tiles
