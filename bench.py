@@ -452,7 +452,7 @@ def main():
             rl["traffic"] = int(sum(h["hbm_bytes_per_launch"] * h["dispatches"] for h in hit) / nd)
             rl["traffic_unit"] = "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
             rl["traffic_source"] = f"{src} (rocprofv3 --pmc passes of this command on libmdtile {running[:12]})"
-            ck = [h for h in hit if h.get("clock_GHz")]
+            ck = [h for h in hit if h.get("clock_GHz") and h["clock_GHz"] <= 2.45]      # (summaries of older passes carry 3-17 "GHz" for us-scale kernels)
             if ck:
                 rl["clock_GHz_measured"] = round(sum(h["clock_GHz"] * h["dispatches"] for h in ck) / max(1, sum(h["dispatches"] for h in ck)), 3)
                 rl["clock_source"] = "GRBM_GUI_ACTIVE / 8 XCDs / kernel duration in the FETCH_SIZE pass; `peak` is quoted at 2.4 GHz"

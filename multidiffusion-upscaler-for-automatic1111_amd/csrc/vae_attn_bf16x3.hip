@@ -489,7 +489,12 @@ static int attn_nsplit(int B, int Tq, int Tk) {
     static const int forced = [] { const char* e = getenv("MDTILE_ATTN_SPLIT"); return e ? atoi(e) : 0; }();
     const int nkb = (Tk + 127) / 128;
     if (forced >= 1 && forced <= 4) return forced <= nkb ? forced : 1;
-    const long long blocks = (long long)B * ((Tq + 127) / 128);
+    // The split is chosen for ONE image of the batch, whatever B is: the key ranges fix the order in which a query's partial sums are
+    // combined, and a tile's result must not depend on which other tiles it is stacked with (scripts/tilevae.py stacks tiles of one
+    // shape along the batch axis; the live-window sweep and the whole-tile sweep stack differently and are compared bit for bit).
+    // More images only add blocks to a launch whose split already fills the chip.
+    (void)B;
+    const long long blocks = (Tq + 127) / 128;
     // launches that fill the chip several times over: 4 key ranges per query block keep the Q working set of an XCD
     // (32 / nsplit query blocks x C x 512 B) inside its L2 -- see the block mapping in k_attn_bf16x3
     if (blocks >= 2 * attn_num_cus() && nkb >= 32) return 4;

@@ -668,58 +668,41 @@ class VAEHook:
                 # a conv launch over one tile fills the 256 CUs in ceil(items / 256) rounds and the last round is mostly empty
                 # (256 -> 256 at 1112^2: 4 900 items = 19.1 rounds, 4 % idle; 512 -> 512 at 278^2: 2.5 rounds, 16 % idle).
                 # 288 GB of HBM hold several tiles' activations at once (3 tiles of 278^2: ~40 GB).
-                # With live windows the sweep is cut in front of a tile's first narrowed upsample conv: up to there tiles stack by SHAPE (the
-                # 1x level and the attention: small planes, where a fuller launch matters most), behind it by (plane, window SIZES) -- each
-                # tile keeps its own window origin, so the first and the last tile of a row share their launches.
-                cut = {i: (min(live[i][0]) if live[i][0] else None) for i in mine}
-                carry: Dict[int, tuple] = {}         # tile -> (x, xrec) in front of steps[cut]
+                # Tiles stack by (shape, window SIZES of their narrowed upsample convs): each tile keeps its own window ORIGIN
+                # (mdtile_upconv2d_rec_window takes one per image), so e.g. the interior tiles of every row share their launches.  A chunk
+                # runs start to finish in ONE pass -- round 3 cut the sweep in front of the first narrowed conv to stack the 1x level by
+                # shape alone and re-stacked the halves with torch.cat: six 0.57 GB copies per 8K decode, more than the fuller launches saved.
+                rep_cache: Dict[int, tuple] = {1: (frozen, coefs)}
 
-                def rep(T):
-                    return (frozen, coefs) if T == 1 else ([(v.repeat(T), m.repeat(T)) for v, m in frozen], [c.repeat(T, 1, 1) for c in coefs])
+                def rep(T):                          # frozen statistics / coefficient rows of a T-deep stack (built once per depth)
+                    if T not in rep_cache:
+                        rep_cache[T] = ([(v.repeat(T), m.repeat(T)) for v, m in frozen], [c.repeat(T, 1, 1) for c in coefs])
+                    return rep_cache[T]
 
                 def regather(chunk):                 # inputs that were folded into a stacked copy: cut them out of z again
                     for i in chunk:
                         b = in_bboxes[i]
                         tiles[i].x = E.gather_rect(z, b[0], b[2], b[1] - b[0], b[3] - b[2])
 
-                def head(chunk):
-                    T, k0 = len(chunk), cut[chunk[0]]
-                    xb = tiles[chunk[0]].x if T == 1 else torch.cat([tiles[i].x for i in chunk], dim=0)
+                def run_stack(chunk):
+                    T = len(chunk)
+                    xb = tiles[chunk[0]].x if T == 1 else torch.cat([tiles[i].x for i in chunk], dim=0)     # (4-channel latent tiles: KBs)
                     fz, cf = rep(T)
                     if T > 1:
                         for i in chunk:
                             tiles[i].x = None          # the stacked copy is the live one
-                    if k0 is None:                     # nothing to shed: the whole sweep
-                        yb = self._run_tile_rec(steps, xb, fz, cf, norm_ord)
-                        for t, i in enumerate(chunk):
-                            tiles[i].x = yb[t * N:(t + 1) * N]
-                            finish(i)
-                        return
-                    xh, rh = self._run_tile_rec(steps, xb, fz, cf, norm_ord, None, 0, k0)
-                    for t, i in enumerate(chunk):
-                        carry[i] = (None if xh is None else xh[t * N:(t + 1) * N], None if rh is None else rh.batch_slice(t * N, (t + 1) * N))
-                        tiles[i].x = None
-
-                def tail(chunk):
-                    T, k0 = len(chunk), cut[chunk[0]]
-                    xs, rs = [carry[i][0] for i in chunk], [carry[i][1] for i in chunk]
-                    xb = None if xs[0] is None else (xs[0] if T == 1 else torch.cat(xs, dim=0))
-                    rb = None if rs[0] is None else type(rs[0]).cat(rs)
-                    fz, cf = rep(T)
+                    w0 = live[chunk[0]][0]
                     wins = {k: ([live[i][0][k][0] for i in chunk for _ in range(N)], [live[i][0][k][1] for i in chunk for _ in range(N)], w[2], w[3])
-                            for k, w in live[chunk[0]][0].items()}
-                    yb = self._run_tile_rec(steps, xb, fz, cf, norm_ord, wins, k0, None, rb)
+                            for k, w in w0.items()} if w0 else None
+                    yb = self._run_tile_rec(steps, xb, fz, cf, norm_ord, wins)
                     for t, i in enumerate(chunk):
                         tiles[i].x = yb[t * N:(t + 1) * N]
-                        del carry[i]
                         finish(i)
 
                 def sweep(groups, run_chunk, restore, origins: bool):
                     nonlocal interrupted
                     for key in sorted(groups, key=lambda kk: -len(groups[kk])):
                         ids = groups[key]
-                        # upstream sizes the TILE so that ONE tile's activations fit the card (:79-99); stacking is only taken when the
-                        # stacked sweep fits what is free right now, and a sweep that still runs out of memory is repeated tile by tile
                         tb = self._tile_batch_that_fits(N, key[:2], dev)
                         if origins and tb * N > 8:
                             tb = max(1, 8 // N)        # mdtile_upconv2d_rec_window keeps 8 window origins per launch
@@ -743,13 +726,8 @@ class VAEHook:
 
                 groups: Dict[tuple, List[int]] = {}
                 for i in mine:
-                    groups.setdefault(tuple(tiles[i].x.shape[2:]) + (cut[i],), []).append(i)
-                sweep(groups, head, regather, False)
-                if not interrupted and carry:
-                    groups = {}
-                    for i in sorted(carry):
-                        groups.setdefault(tuple(in_bboxes[i][k + 1] - in_bboxes[i][k] for k in (2, 0)) + tuple((k, w[2], w[3]) for k, w in sorted(live[i][0].items())), []).append(i)
-                    sweep(groups, tail, lambda chunk: None, True)      # (the carried planes of a failed stack are still there)
+                    groups.setdefault(tuple(tiles[i].x.shape[2:]) + tuple((k, w[2], w[3]) for k, w in sorted(live[i][0].items())), []).append(i)
+                sweep(groups, run_stack, regather, True)
                 mine = []        # all done (or interrupted)
             for i in mine:
                 if state.interrupted:

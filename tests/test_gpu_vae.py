@@ -384,13 +384,14 @@ def test_tiled_decode_half_precision_vae(plugin, cuda):
     assert _rel(out.float().cpu(), ref) < 2e-3                          # + one fp16 rounding of the output
 
 
-@pytest.mark.parametrize("live,L,n_stacked,n_single", [(False, 64, 3, 9), (True, 80, 3 + 5, 16 + 16)], ids=["whole_tiles", "live_windows"])
+@pytest.mark.parametrize("live,L,n_stacked,n_single", [(False, 64, 3, 9), (True, 80, 1 + 4, 16)], ids=["whole_tiles", "live_windows"])
 def test_stacked_sweep_falls_back_to_single_tiles_on_oom(plugin, cuda, monkeypatch, live, L, n_stacked, n_single):
     """Fast mode stacks tiles of one shape along the batch axis (TILE_BATCH); a stacked sweep that runs out of memory is repeated tile by
     tile and the result is the same image (upstream sizes the tile for ONE tile's activations, scripts/tilevae.py:79-99).
     whole tiles, 64^2 latent at tile 16: 9 tiles = 4 of 38x38, 2 + 2 of 32x38 / 38x32, 1 of 32x32.
-    live windows, 80^2: 16 tiles; the sweep is cut in front of the first narrowed upsample conv: its head stacks by shape (9 + 3 + 3 + 1 tiles),
-    its tail by (shape, window sizes) = 4 inner tiles, 4 x 2 edge tiles, 4 x 1 corner tiles."""
+    live windows, 80^2: 16 tiles stacked by (shape, window sizes) = 4 inner tiles (one failed stack of 3), 4 x 2 edge tiles (four failed
+    stacks of 2), 4 x 1 corner tiles; every tile then runs singly, once (round 4: one pass per chunk, no cut in front of the first
+    narrowed upsample conv any more)."""
     tv = plugin.tilevae
     dec = ld.make_decoder(4).to(cuda)
     dec.original_forward = dec.forward
@@ -482,3 +483,22 @@ def test_attention_forced_to_exact_fp32_by_env_alone(cuda):
     env = dict(os.environ, MDTILE_ATTN_MODE="f32")
     r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "attn-f32-env ok" in r.stdout, r.stdout[-3000:]
+
+
+@pytest.mark.parametrize("C,T", [(512, 1444), (512, 7396), (128, 3000)])
+def test_attention_of_a_stacked_batch_is_bit_identical_to_the_single_images(plugin, cuda, C, T):
+    """A tile's attention must not depend on the tiles it is stacked with (scripts/tilevae.py stacks tiles along the batch axis; the
+    live-window and the whole-tile sweeps stack differently and their images are compared bit for bit): the key-range split, which
+    fixes the order a query's partial sums are combined in, is chosen per image (csrc/vae_attn_bf16x3.hip: attn_nsplit)."""
+    E = plugin.engine
+    g = torch.Generator(device="cpu").manual_seed(C + T)
+    q = torch.randn(3, C, T, generator=g).to(cuda)
+    k = torch.randn(3, C, T, generator=g).to(cuda)
+    v = torch.randn(3, C, T, generator=g).to(cuda)
+    scale = float(C ** -0.5)
+    whole = E.vae_attn(q, k, v, scale, v_channel_major=True)
+    for b in range(3):
+        one = E.vae_attn(q[b:b + 1].contiguous(), k[b:b + 1].contiguous(), v[b:b + 1].contiguous(), scale, v_channel_major=True)
+        assert torch.equal(whole[b:b + 1], one), f"image {b} of the stack differs from its own launch"
+    two = E.vae_attn(q[:2].contiguous(), k[:2].contiguous(), v[:2].contiguous(), scale, v_channel_major=True)
+    assert torch.equal(whole[:2], two)

@@ -10,9 +10,14 @@ import collections, csv, glob, gzip, json, os, sys
 XCDS = 8
 
 
+MIN_CLOCK_KERNEL_NS = 1.0e6      # GRBM_GUI_ACTIVE counts for the whole counter window around a dispatch: for kernels shorter than ~1 ms the quotient
+#                                   comes out at 3 - 17 "GHz" (round 3 printed 3.04 for the 20 us blend); only long kernels fill the window
+
+
 def load_clock(d):
-    """GRBM_GUI_ACTIVE (summed over the 8 XCDs) / kernel duration of the same dispatch -> GHz per kernel, when the pass collected it."""
-    agg = collections.defaultdict(lambda: [0.0, 0.0])
+    """GRBM_GUI_ACTIVE (summed over the 8 XCDs) / kernel duration of the same dispatch -> GHz per kernel, when the pass collected it.
+    Kernels whose average dispatch is shorter than MIN_CLOCK_KERNEL_NS, or whose quotient exceeds the chip's 2.4 GHz, get no clock."""
+    agg = collections.defaultdict(lambda: [0.0, 0.0, 0])
     for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv*"), recursive=True):
         op = gzip.open if fn.endswith(".gz") else open
         with op(fn, "rt") as f:
@@ -22,7 +27,8 @@ def load_clock(d):
                 a = agg[r["Kernel_Name"]]
                 a[0] += float(r["Counter_Value"]) / XCDS
                 a[1] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
-    return {k: v[0] / v[1] for k, v in agg.items() if v[1] > 0}
+                a[2] += 1
+    return {k: v[0] / v[1] for k, v in agg.items() if v[1] > 0 and v[1] / v[2] >= MIN_CLOCK_KERNEL_NS and v[0] / v[1] <= 2.45}
 
 
 def libmdtile_digest():
@@ -63,7 +69,7 @@ def main():
             kernels[k[:160]]["clock_GHz"] = round(clk[k], 4)
     with open(out, "w") as f:
         json.dump({"note": "HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KB, separate rocprofv3 --pmc passes; clock_GHz = GRBM_GUI_ACTIVE / 8 XCDs / "
-                           "kernel duration in the FETCH_SIZE pass", "libmdtile_digest": libmdtile_digest(), "kernels": kernels}, f, indent=1)
+                           "kernel duration in the FETCH_SIZE pass, only for kernels of >= 1 ms per dispatch (the counter window of a shorter kernel is mostly not the kernel)", "libmdtile_digest": libmdtile_digest(), "kernels": kernels}, f, indent=1)
     for k, v in list(kernels.items())[:12]:
         print(f"{k[:80]:80s} n={v['dispatches']:5d}  {v['hbm_bytes_per_launch'] / 1e6:10.1f} MB/launch")
 
