@@ -274,8 +274,11 @@ int mdtile_conv2d_gn(const float* d_x, const float* d_coef, const float* d_w_pac
 
 /* Record-image conv path (fast mode: every GroupNorm's statistics are frozen before the tiles run, tilevae.py:464-505, 542-563).
  * A "record image" of an activation [B, C, H, W] (C % 32 == 0) is its split-bf16 form in MFMA fragment order with a
- * 1-pixel zero border:  rec[b][hl][C/8][H+2][W+2] x 16 bytes, hl = 0: bf16(x), hl = 1: bf16(x - hi); plane p = 2*kstep + kg
+ * 1-pixel zero border:  rec[b][hl][C/8][H+2][pitch] x 16 bytes, hl = 0: bf16(x), hl = 1: bf16(x - hi); plane p = 2*kstep + kg
  * holds channels 32*(kstep>>1) + 16*(kstep&1) + 4*kg + (j&3) + 8*(j>>2), j = 0..7  -- 4 bytes per element, like fp32.
+ * Rows: pitch = (W + 9 + 7) & ~7 records; pixel x sits at column x + 8, the border records at columns 7 and W + 8, the rest of a row
+ * is padding nobody reads -- so that every 32-pixel run the kernels store is four whole 128-byte lines (round 4; the size is
+ * opaque to callers: mdtile_rec_size).
  * The PRODUCER applies the following norm's (a, s) + SiLU (custom_group_norm + inplace_nonlinearity, tilevae.py:218-245,
  * 102-104) and splits; the consuming conv stages its input by DMA only.
  *   mdtile_rec_size            : bytes of the record image of [B, C, H, W]

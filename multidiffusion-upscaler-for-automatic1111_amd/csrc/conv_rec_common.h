@@ -10,6 +10,16 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace mdt {
 
+// Geometry of a record image (round 4).  A plane has H + 2 rows (one zero-border row above and below) of rec_pitch(W) records;
+// pixel x sits at column x + 8, the zero-border records at columns 7 and W + 8; columns 0-6 and those behind W + 8 are padding that
+// nothing reads.  The pitch is a multiple of 8 records, so every 32-pixel run a wave stores (x0 % 32 == 0) is FOUR WHOLE 128-byte lines.
+// Until round 4 the interior started at column 1 of a W + 2 pitch: every run began 16 bytes into a line and ended 16 bytes into
+// another, i.e. two partial 64-byte sectors per 512 bytes written (probes/cu_mempipe_probe.cpp: 2 x 512 B runs shifted by 16 B stream
+// at 15 GB/s per CU chip-wide, aligned ones at 28).  Measured on the conv itself the aligned rows are worth 1-2 % of an item
+// (profiles/r4n): its store epilogue is bound elsewhere, but whole-line writes are the right layout anyway.
+constexpr int REC_COL0 = 7;                                                            // column of the left border record
+__host__ __device__ inline int rec_pitch(int W) { return (W + 2 + REC_COL0 + 7) & ~7; }
+
 constexpr int REC_WIN_MAXB = 8;   // images per launch that may carry a window origin of their own (stacked tiles of one shape)
 
 struct ConvRParams {
@@ -29,7 +39,8 @@ struct ConvRParams {
     unsigned skew_ticks;      // start-up delay (100 MHz ticks) of the block that arrives SECOND on its CU: puts the pair half an item out of phase
     unsigned* cu_ctr;         // [8 XCDs x 256 hardware CU ids] arrival counters (never reset: only the parity is used); null = skew by block index
     unsigned* census;         // probing: [gridDim.x] hardware id of the CU each block ran on | arrival parity << 31, or null
-    int dbg;                  // probing (MDTILE_REC_DBG): bit 0 = skip the epilogue (K loop only: nothing is written)
+    int dbg;                  // probing (MDTILE_REC_DBG): bit 0 = skip the epilogue (K loop only: nothing is written); bit 3 = block 0 of the
+                              // one-block kernel writes s_memtime stamps per wave and item to `census` (probes/conv_item_timeline.py)
 };
 
 }  // namespace mdt
@@ -80,7 +91,7 @@ struct EpiCtx {
     bool has_bias, has_act;
     int Cout, H, W;      // output size
     int b, kg;
-    size_t HW, planeO;   // fp32 plane, record plane ((H+2)*(W+2))
+    size_t HW, planeO;   // fp32 plane, record plane ((H + 2) * rec_pitch(W))
     int WpO;
 };
 
@@ -176,7 +187,7 @@ __device__ __forceinline__ void epilogue_mtile(const EpiCtx& E, const u32x4* ec,
                     }
                     u32x4 hi, lo;
                     split8r(t8, hi, lo);
-                    const size_t at = pl + (size_t)(y + 1) * E.WpO + (x + e + 1);
+                    const size_t at = pl + (size_t)(y + 1) * E.WpO + (x + e + 1 + mdt::REC_COL0);
                     yb[at] = hi;
                     yb[(size_t)Pn * E.planeO + at] = lo;
                 }
@@ -185,7 +196,7 @@ __device__ __forceinline__ void epilogue_mtile(const EpiCtx& E, const u32x4* ec,
                 if (left || right || top || bot) {
                     const u32x4 z = {0u, 0u, 0u, 0u};
                     auto zrec = [&](int py, int px) {
-                        const size_t at = pl + (size_t)py * E.WpO + px;
+                        const size_t at = pl + (size_t)py * E.WpO + px + mdt::REC_COL0;      // (px: padded column, 0 = left border)
                         yb[at] = z;
                         yb[(size_t)Pn * E.planeO + at] = z;
                     };

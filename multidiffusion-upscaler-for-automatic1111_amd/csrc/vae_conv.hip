@@ -240,6 +240,7 @@ int conv_rec_narrow_pack(const float* d_w_oihw, void* d_out, int cout, int cin, 
 // vae_conv_rec.hip
 bool conv_rec_supported(int cout, int cin, int ksize);
 size_t rec_image_bytes(int B, int C, int H, int W);
+size_t rec_plane_records(int H, int W);
 int rec_from_f32_launch(const float* d_x, const float* d_coef, void* d_rec, int B, int C, int H, int W, hipStream_t s);
 int rec_to_f32_launch(const void* d_rec, float* d_x, int B, int C, int H, int W, hipStream_t s);
 int conv_rec_launch(const void* d_xrec, const void* d_w_rec, const float* d_bias, const float* d_res, float* d_y32, void* d_yrec,
@@ -335,7 +336,7 @@ extern "C" size_t mdtile_rec_size(int B, int C, int H, int W) {
 static bool rec_image_ok(int B, int C, int H, int W) {
     // per-lane DMA offsets are 32-bit BYTE offsets inside one pair of planes; record indices of a whole image stay below 2^32
     return B > 0 && C > 0 && C % 32 == 0 && H > 0 && W > 0 && H + 2 <= 65535 && (size_t)B * (C / 8) <= 65535 &&
-           2 * (size_t)(H + 2) * (W + 2) * 16 < ((size_t)1 << 32);
+           2 * rec_plane_records(H, W) * 16 < ((size_t)1 << 32);
 }
 
 extern "C" int mdtile_rec_from_f32(const float* d_x, const float* d_coef, void* d_rec, int B, int C, int H, int W, mdtile_stream_t stream) {

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rec(const ConvRParams P) {
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kg = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wr = wave / WM;
-    const int Hp = P.H + 2, Wp = P.W + 2, Pn = P.Cin >> 3;
+    const int Hp = P.H + 2, Wp = rec_pitch(P.W), Pn = P.Cin >> 3;
     const size_t plane = (size_t)Hp * Wp;
 
     // work -> (sample, pixel tile, cout block).  Workgroups go to XCDs round-robin (id % 8) and grid % 8 == 0 whenever a block
@@ -96,9 +96,9 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rec(const ConvRParams P) {
             if (s >= IS::HALF) s = IS::HALF - 1;            // pad lanes shadow the last record (they land in the pad area)
             const int g = s / (ROWS * COLS), p = s - g * (ROWS * COLS);
             const int r = p / COLS, c = p - r * COLS;
-            int pr = it.y0 + r, pc = it.x0 + c;             // padded coordinates (image row y0 + r - 1)
+            int pr = it.y0 + r, pc = it.x0 + c;             // padded coordinates (image row y0 + r - 1, image column x0 + c - 1)
             pr = pr < Hp ? pr : Hp - 1;                     // ragged block edge: clamp onto the zero border
-            pc = pc < Wp ? pc : Wp - 1;
+            pc = (pc < P.W + 1 ? pc : P.W + 1) + REC_COL0;  // (column of the record image: the left border sits at REC_COL0)
             ioff[i] = (unsigned)(((size_t)g * plane + (size_t)pr * Wp + pc) * 16);
         }
     };
@@ -165,11 +165,20 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rec(const ConvRParams P) {
     const int nph = P.NK * 3;
     int par = 0;
 
+    // probing (MDTILE_REC_DBG bit 3 + MDTILE_REC_STAMPS=<device address>): block 0 records s_memtime per wave and item at
+    //   0 item start (behind the barrier) | 1 K loop done | 2 epilogue code done (stores issued) | 4 vmcnt(0) + barrier of the next item passed
+    unsigned long long* const stamps = (P.dbg & 8) && P.census && blockIdx.x == 0 ? reinterpret_cast<unsigned long long*>(P.census) : nullptr;
+    int item_no = 0;
+    auto stamp = [&](int k) {
+        if (stamps && lane == 0 && item_no < 64) stamps[(item_no * 8 + wave) * 8 + k] = __builtin_readcyclecounter();
+    };
     while (true) {
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces of the item's first operands have landed
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (item_no > 0) { --item_no; stamp(4); ++item_no; }
+        stamp(0);
         load_fw(0, 0, 0);
         load_fx(0, 0, 0, 0, 0);
         const int work_n = next_valid(work + gridDim.x, nxt);
@@ -246,6 +255,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rec(const ConvRParams P) {
             }
         }
 
+        stamp(1);
         EpiCtx E;
         E.res = P.res; E.y32 = P.y32; E.yrec = P.yrec;
         E.has_bias = P.bias != nullptr; E.has_act = P.yrec != nullptr && P.coef != nullptr;
@@ -260,6 +270,8 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rec(const ConvRParams P) {
             for (int m = 0; m < MW; ++m)
                 epilogue_mtile<1, NROW>(E, ec_l + par * EC_REC, acc[m], wm * MW + m, cur.cb * MT + wm * MW + m, ys, x, x < P.W);
         }
+        stamp(2);
+        ++item_no;
         if (work_n >= total) break;
         work = work_n;
         cur = nxt;
@@ -289,7 +301,7 @@ __global__ __launch_bounds__(512, 2) void k_upconv_rec(const ConvRParams P) {
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kg = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wr = wave / WM;
-    const int Hp = P.HinF + 2, Wp = P.WinF + 2, Pn = P.Cin >> 3;      // pitches of the WHOLE input image; items tile its window
+    const int Hp = P.HinF + 2, Wp = rec_pitch(P.WinF), Pn = P.Cin >> 3;      // pitches of the WHOLE input image; items tile its window
     const size_t plane = (size_t)Hp * Wp;
 
     struct Item {
@@ -321,7 +333,7 @@ __global__ __launch_bounds__(512, 2) void k_upconv_rec(const ConvRParams P) {
             const int r = p / COLS, c = p - r * COLS;
             int pr = P.iy0[it.b & (REC_WIN_MAXB - 1)] + it.y0 + r, pc = P.ix0[it.b & (REC_WIN_MAXB - 1)] + it.x0 + c;     // inside the window's own border: the image's real neighbours
             pr = pr < Hp ? pr : Hp - 1;
-            pc = pc < Wp ? pc : Wp - 1;
+            pc = (pc < P.WinF + 1 ? pc : P.WinF + 1) + REC_COL0;
             ioff[i] = (unsigned)(((size_t)g * plane + (size_t)pr * Wp + pc) * 16);
         }
     };
@@ -470,7 +482,7 @@ __global__ __launch_bounds__(512, 2) void k_upconv_rec(const ConvRParams P) {
         E.res = P.res; E.y32 = P.y32; E.yrec = P.yrec;
         E.has_bias = P.bias != nullptr; E.has_act = P.yrec != nullptr && P.coef != nullptr;
         E.Cout = P.Cout; E.H = P.H; E.W = P.W; E.b = cur.b; E.kg = kg;
-        E.HW = (size_t)P.H * P.W; E.planeO = (size_t)(P.H + 2) * (P.W + 2); E.WpO = P.W + 2;
+        E.HW = (size_t)P.H * P.W; E.planeO = (size_t)(P.H + 2) * rec_pitch(P.W); E.WpO = rec_pitch(P.W);
         const int xi = cur.x0 + l31;
         int ys[NROW];
 #pragma unroll
@@ -499,12 +511,12 @@ __global__ __launch_bounds__(512, 2) void k_upconv_rec(const ConvRParams P) {
 // One thread = one (pixel, plane) of the PADDED image; border threads write the zero records.
 __global__ __launch_bounds__(256) void k_rec_from_f32(const float* __restrict__ x, const float* __restrict__ coef, u32x4* __restrict__ rec,
                                                       int C, int H, int W) {
-    const int Wp = W + 2, Hp = H + 2, Pn = C >> 3;
-    const int px = blockIdx.x * 256 + threadIdx.x, py = blockIdx.y;
+    const int Wp = rec_pitch(W), Hp = H + 2, Pn = C >> 3;
+    const int px = blockIdx.x * 256 + threadIdx.x, py = blockIdx.y;      // padded coordinates: (0, 0) = the top-left border record
     const int bp = blockIdx.z, b = bp / Pn, p = bp - b * Pn;
-    if (px >= Wp) return;
+    if (px >= W + 2) return;
     const size_t planeO = (size_t)Hp * Wp;
-    u32x4* hi_p = rec + ((size_t)b * 2 * Pn + p) * planeO + (size_t)py * Wp + px;
+    u32x4* hi_p = rec + ((size_t)b * 2 * Pn + p) * planeO + (size_t)py * Wp + px + REC_COL0;
     u32x4* lo_p = hi_p + (size_t)Pn * planeO;
     u32x4 hi = {0u, 0u, 0u, 0u}, lo = {0u, 0u, 0u, 0u};
     if (px >= 1 && px <= W && py >= 1 && py <= H) {
@@ -527,12 +539,12 @@ __global__ __launch_bounds__(256) void k_rec_from_f32(const float* __restrict__ 
 
 // record image -> fp32 NCHW (hi + lo): inspection / tests
 __global__ __launch_bounds__(256) void k_rec_to_f32(const u32x4* __restrict__ rec, float* __restrict__ x, int C, int H, int W) {
-    const int Wp = W + 2, Hp = H + 2, Pn = C >> 3;
+    const int Wp = rec_pitch(W), Hp = H + 2, Pn = C >> 3;
     const int px = blockIdx.x * 256 + threadIdx.x, py = blockIdx.y;
     const int bp = blockIdx.z, b = bp / Pn, p = bp - b * Pn;
     if (px >= W) return;
     const size_t planeO = (size_t)Hp * Wp;
-    const u32x4* hi_p = rec + ((size_t)b * 2 * Pn + p) * planeO + (size_t)(py + 1) * Wp + (px + 1);
+    const u32x4* hi_p = rec + ((size_t)b * 2 * Pn + p) * planeO + (size_t)(py + 1) * Wp + (px + 1 + REC_COL0);
     const bf16x8 h = __builtin_bit_cast(bf16x8, *hi_p), l = __builtin_bit_cast(bf16x8, hi_p[(size_t)Pn * planeO]);
     const int ks = p >> 1, g = p & 1;
     const int c0 = 32 * (ks >> 1) + 16 * (ks & 1) + 4 * g;
@@ -594,7 +606,9 @@ static bool rec_two_blocks(long long items16, long long items8, int cus, int up)
 
 bool conv_rec_supported(int cout, int cin, int ksize) { return ksize == 3 && cin % 32 == 0 && (cout % 128 == 0 || (cout >= 1 && cout < 32)); }
 
-size_t rec_image_bytes(int B, int C, int H, int W) { return (size_t)B * C * (H + 2) * (W + 2) * 4; }
+size_t rec_image_bytes(int B, int C, int H, int W) { return (size_t)B * C * (H + 2) * rec_pitch(W) * 4; }
+
+size_t rec_plane_records(int H, int W) { return (size_t)(H + 2) * rec_pitch(W); }
 
 int rec_from_f32_launch(const float* d_x, const float* d_coef, void* d_rec, int B, int C, int H, int W, hipStream_t s) {
     dim3 grid(cdiv(W + 2, 256), H + 2, B * (C / 8));
@@ -628,7 +642,9 @@ int conv_rec_launch(const void* d_xrec, const void* d_w_rec, const float* d_bias
     P.NK = cin / 16;
     P.skew_ticks = 0; P.cu_ctr = nullptr; P.census = nullptr;
     P.dbg = 0;
-    if (const char* e = getenv("MDTILE_REC_DBG")) P.dbg = atoi(e);      // probing only (probes/conv_rec2_ab.py): see ConvRParams::dbg
+    if (const char* e = getenv("MDTILE_REC_DBG")) P.dbg = atoi(e);      // probing only (probes/conv_rec_diag.py, conv_item_timeline.py): see ConvRParams::dbg
+    if (P.dbg & 8)
+        if (const char* e = getenv("MDTILE_REC_STAMPS")) P.census = reinterpret_cast<unsigned*>((uintptr_t)strtoull(e, nullptr, 16));
     if (up) P.w = (const u32x4*)d_w_rec + conv_bf16x3_direct_records(cout, cin);
     if (cout % 128 == 0 && rec_persistent()) {
         const int cus = num_cus() / 8 * 8;

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_rec2(const ConvRParams P) {
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kg = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wr = wave / WM;
-    const int Hp = P.H + 2, Wp = P.W + 2, Pn = P.Cin >> 3;
+    const int Hp = P.H + 2, Wp = rec_pitch(P.W), Pn = P.Cin >> 3;
     const size_t plane = (size_t)Hp * Wp;
 
     // work -> (sample, pixel tile, cout block): as in k_conv3x3_rec (grid % 8 == 0 => `work % 8` is this block's XCD for all its
@@ -125,9 +125,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_rec2(const ConvRParams P) {
             if (s >= IS::HALF) s = IS::HALF - 1;            // pad lanes shadow the last record (they land in the pad area)
             const int g = s / (ROWS * COLS), p = s - g * (ROWS * COLS);
             const int r = p / COLS, c = p - r * COLS;
-            int pr = it.y0 + r, pc = it.x0 + c;             // padded coordinates (image row y0 + r - 1)
+            int pr = it.y0 + r, pc = it.x0 + c;             // padded coordinates (image row y0 + r - 1, image column x0 + c - 1)
             pr = pr < Hp ? pr : Hp - 1;                     // ragged block edge: clamp onto the zero border
-            pc = pc < Wp ? pc : Wp - 1;
+            pc = (pc < P.W + 1 ? pc : P.W + 1) + REC_COL0;  // (column of the record image: the left border sits at REC_COL0)
             ioff[i] = (unsigned)(((size_t)g * plane + (size_t)pr * Wp + pc) * 16);
         }
     };
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void k_upconv_rec2(const ConvRParams P) {
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kg = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wr = wave / WM;
-    const int Hp = P.HinF + 2, Wp = P.WinF + 2, Pn = P.Cin >> 3;      // pitches of the WHOLE input image; items tile its window
+    const int Hp = P.HinF + 2, Wp = rec_pitch(P.WinF), Pn = P.Cin >> 3;      // pitches of the WHOLE input image; items tile its window
     const size_t plane = (size_t)Hp * Wp;
 
     struct Item {
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void k_upconv_rec2(const ConvRParams P) {
             const int r = p / COLS, c = p - r * COLS;
             int pr = P.iy0[it.b & (REC_WIN_MAXB - 1)] + it.y0 + r, pc = P.ix0[it.b & (REC_WIN_MAXB - 1)] + it.x0 + c;   // inside the window's own border: the image's real neighbours
             pr = pr < Hp ? pr : Hp - 1;
-            pc = pc < Wp ? pc : Wp - 1;
+            pc = (pc < P.WinF + 1 ? pc : P.WinF + 1) + REC_COL0;
             ioff[i] = (unsigned)(((size_t)g * plane + (size_t)pr * Wp + pc) * 16);
         }
     };
@@ -540,7 +540,7 @@ __global__ __launch_bounds__(256, 2) void k_upconv_rec2(const ConvRParams P) {
         E.res = P.res; E.y32 = P.y32; E.yrec = P.yrec;
         E.has_bias = P.bias != nullptr; E.has_act = P.yrec != nullptr && P.coef != nullptr;
         E.Cout = P.Cout; E.H = P.H; E.W = P.W; E.b = cur.b; E.kg = kg;
-        E.HW = (size_t)P.H * P.W; E.planeO = (size_t)(P.H + 2) * (P.W + 2); E.WpO = P.W + 2;
+        E.HW = (size_t)P.H * P.W; E.planeO = (size_t)(P.H + 2) * rec_pitch(P.W); E.WpO = rec_pitch(P.W);
         const int xi = cur.x0 + l31;
         int ys[NROW];
 #pragma unroll

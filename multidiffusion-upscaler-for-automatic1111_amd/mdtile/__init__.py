@@ -647,7 +647,21 @@ class RecImage:
         self.shape = (B, C, H, W)
         self.data = torch.empty(n // 4, dtype=torch.int32, device=device)
 
-    # the image is batch-major (rec[b][hl][C/8][H+2][W+2]): samples can be cut out of / stacked into it without touching the records
+    REC_COL0 = 7          # csrc/conv_rec_common.h: column of the left border record; pixel x sits at column x + 8
+
+    @staticmethod
+    def pitch(W: int) -> int:
+        """records per row of a plane: W + 2 logical columns behind 7 columns of padding, rounded up to whole 128-byte lines"""
+        return (int(W) + 2 + RecImage.REC_COL0 + 7) & ~7
+
+    def records(self) -> torch.Tensor:
+        """[B, 2 (hi | lo), C / 8, H + 2, W + 2, 4] int32 view of the LOGICAL image: border records included, the row padding (never
+        written, never read) left out -- what two record images are compared on."""
+        B, C, H, W = self.shape
+        full = self.data.view(B, 2, C // 8, H + 2, RecImage.pitch(W), 4)
+        return full[:, :, :, :, RecImage.REC_COL0:RecImage.REC_COL0 + W + 2, :]
+
+    # the image is batch-major (rec[b][hl][C/8][H+2][pitch]): samples can be cut out of / stacked into it without touching the records
     def batch_slice(self, b0: int, b1: int) -> "RecImage":
         B, C, H, W = self.shape
         assert 0 <= b0 < b1 <= B

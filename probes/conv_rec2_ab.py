@@ -108,7 +108,7 @@ for shape in SHAPES:
         t1 = timeit(fn)
         setenv(MDTILE_REC_BLOCKS=2, MDTILE_REC2_SKEW=None, MDTILE_REC2_SKEW_PCT=None)
         y2, r2 = fn()
-        same = (y1 is None or torch.equal(y1, y2)) and torch.equal(r1.data, r2.data)
+        same = (y1 is None or torch.equal(y1, y2)) and torch.equal(r1.records(), r2.records())
         t2 = timeit(fn)
         line = f"   {name}: one block {t1:7.3f} ms {flops / t1 * 1e-9:6.1f} TF | two blocks {t2:7.3f} ms {flops / t2 * 1e-9:6.1f} TF ({(t1 / t2 - 1) * 100:+5.1f} %) bit-identical {same}"
         if SWEEP:

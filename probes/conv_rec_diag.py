@@ -12,7 +12,8 @@ sys.path.insert(0, ROOT)
 import mdtile as E
 
 dev = torch.device("cuda:0")
-SHAPES = [(512, 512, 556, 556), (512, 512, 278, 278), (256, 256, 1112, 1112), (512, 256, 1112, 1112), (128, 128, 2224, 2224)]
+SHAPES = [(512, 512, 556, 556), (512, 512, 278, 278), (256, 256, 1112, 1112), (512, 256, 1112, 1112), (128, 128, 2224, 2224),
+          (128, 128, 128, 128, 304), (128, 128, 512, 512, 19)]      # 5, 6: the pixel count of 2224^2 as many small images (planes of 64 KB / 1 MB: few pages per item)
 if "--shapes" in sys.argv:
     SHAPES = [SHAPES[int(i)] for i in sys.argv[sys.argv.index("--shapes") + 1].split(",")]
 
@@ -41,32 +42,35 @@ def setenv(**kw):
 
 
 torch.manual_seed(0)
-for cin, cout, H, W in SHAPES:
+for shape in SHAPES:
+    cin, cout, H, W = shape[:4]
+    B = shape[4] if len(shape) > 4 else 1
     conv = torch.nn.Conv2d(cin, cout, 3, 1, 1).to(dev)
     pc = E.PackedConv(conv.weight.detach(), conv.bias.detach())
-    x = torch.randn(1, cin, H, W, device=dev)
-    res = torch.randn(1, cout, H, W, device=dev)
-    ci = torch.stack([torch.rand(1, cin, device=dev) + 0.5, torch.randn(1, cin, device=dev) * 0.3], dim=1).contiguous()
-    co = torch.stack([torch.rand(1, cout, device=dev) + 0.5, torch.randn(1, cout, device=dev) * 0.3], dim=1).contiguous()
+    x = torch.randn(B, cin, H, W, device=dev)
+    res = torch.randn(B, cout, H, W, device=dev)
+    ci = torch.stack([torch.rand(B, cin, device=dev) + 0.5, torch.randn(B, cin, device=dev) * 0.3], dim=1).contiguous()
+    co = torch.stack([torch.rand(B, cout, device=dev) + 0.5, torch.randn(B, cout, device=dev) * 0.3], dim=1).contiguous()
     xrec = E.rec_from_f32(x, ci)
     rr = lambda: pc.call_rec(xrec, want_f32=False, want_rec=True, rec_coef=co)
     rb = lambda: pc.call_rec(xrec, residual=res, want_f32=True, want_rec=True, rec_coef=co)
-    flops = 2.0 * H * W * cout * cin * 9
+    flops = 2.0 * B * H * W * cout * cin * 9
     ncb = cout // 128
-    print(f"{cin}->{cout} {H}x{W}: per-item times in us (one-block items = 128 couts x 16 rows x 32 px; two-block items are half of that: their times are doubled below)", flush=True)
+    print(f"{cin}->{cout} {H}x{W} B={B}: per-item times in us (one-block items = 128 couts x 16 rows x 32 px; two-block items are half of that: their times are doubled below)", flush=True)
 
     def row(label, blocks, rows, nblk, **env):
-        setenv(MDTILE_REC_BLOCKS=blocks, MDTILE_REC_DBG=None, **env)
+        base = int(os.environ.get("MDTILE_REC_DBG_BASE", "0"))
+        setenv(MDTILE_REC_BLOCKS=blocks, MDTILE_REC_DBG=base or None, **env)
         pt = -(-W // 32) * -(-H // rows)
-        items = -(-pt // 8) * 8 * ncb
+        items = -(-pt // 8) * 8 * ncb * B
         rounds = -(-items // nblk)
         scale = 16 // rows       # per 16-row item equivalent
         out = []
         for fn in (rr, rb):
             t_full = timeit(fn)
-            setenv(MDTILE_REC_DBG=1)
+            setenv(MDTILE_REC_DBG=1 | base)
             t_k = timeit(fn)
-            setenv(MDTILE_REC_DBG=None)
+            setenv(MDTILE_REC_DBG=base or None)
             out.append((t_full, t_k))
         (a, ak), (b, bk) = out
         per = lambda t: t * 1e3 / rounds * scale * (nblk / (256 * (2 if rows == 8 else 1))) if False else t * 1e3 / rounds * scale

@@ -193,8 +193,8 @@ def test_upconv_window_equals_the_same_pixels_of_the_whole_image_call(plugin, cu
     assert torch.equal(r_win.to_f32(), r_full.to_f32()[:, :, 2 * y0:2 * (y0 + h), 2 * x0:2 * (x0 + w)])
     # the record output is a well-formed image of its own: the same records as the whole-image call inside, a ZERO border around
     # (the next conv's padding -- not the neighbours the whole image has there)
-    dw = r_win.data.view(B, 2, cout // 8, 2 * h + 2, 2 * w + 2, 4)
-    df = r_full.data.view(B, 2, cout // 8, 2 * Hin + 2, 2 * Win + 2, 4)
+    dw = r_win.records()          # [B, 2, cout / 8, 2 h + 2, 2 w + 2, 4]: the logical image incl. its border records
+    df = r_full.records()
     assert torch.equal(dw[:, :, :, 1:-1, 1:-1], df[:, :, :, 1 + 2 * y0:1 + 2 * (y0 + h), 1 + 2 * x0:1 + 2 * (x0 + w)])
     assert not dw[:, :, :, 0].any() and not dw[:, :, :, -1].any() and not dw[:, :, :, :, 0].any() and not dw[:, :, :, :, -1].any()
     # and against torch fp32
@@ -339,4 +339,4 @@ def test_two_blocks_per_cu_kernels_are_bit_identical_to_the_one_block_kernels(pl
         monkeypatch.setenv("MDTILE_REC2_SKEW", skew)
         y2, r2 = pc.call_rec(xrec, residual=rr, upsample2x=up, want_f32=True, want_rec=True, rec_coef=out_coef)
         assert torch.equal(y1, y2), f"fp32 output differs (skew mode {skew}): {_rel(y2, y1)}"
-        assert torch.equal(r1.data, r2.data), f"record output differs (skew mode {skew})"
+        assert torch.equal(r1.records(), r2.records()), f"record output differs (skew mode {skew})"
