@@ -55,6 +55,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = hipcc_path()
     if hipcc is None:
         raise RuntimeError("hipcc not found: libmdtile.so cannot be built (ROCm toolchain required)")
+    if os.path.exists(STAMP):
+        os.remove(STAMP)      # a build that fails half way (link done, assembly guard rejected) must not leave the OLD digest next to a NEW library
     objs = []
     objdir = os.path.join(EXT_ROOT, "build")
     os.makedirs(objdir, exist_ok=True)
