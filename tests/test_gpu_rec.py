@@ -340,3 +340,31 @@ def test_two_blocks_per_cu_kernels_are_bit_identical_to_the_one_block_kernels(pl
         y2, r2 = pc.call_rec(xrec, residual=rr, upsample2x=up, want_f32=True, want_rec=True, rec_coef=out_coef)
         assert torch.equal(y1, y2), f"fp32 output differs (skew mode {skew}): {_rel(y2, y1)}"
         assert torch.equal(r1.records(), r2.records()), f"record output differs (skew mode {skew})"
+
+
+@pytest.mark.parametrize("blocks", ["1", "2"], ids=["one_block_per_cu", "two_blocks_per_cu"])
+def test_upconv_windows_under_both_kernel_families(plugin, cuda, monkeypatch, blocks):
+    """mdtile_upconv2d_rec_window (per-image window origins inside a larger input image, live-window narrowing of the decoder tiles) through
+    the one-block kernel AND the two-blocks-per-CU kernel (csrc/vae_conv_rec2.hip: k_upconv_rec2 tiles the window in 4-row items and reads
+    the whole image's pitch): every image's window equals the same pixels of the whole-image call, fp32 and records, bit for bit."""
+    E = plugin.engine
+    monkeypatch.setenv("MDTILE_REC_BLOCKS", blocks)
+    torch.manual_seed(8)
+    conv = torch.nn.Conv2d(256, 128, 3, 1, 1)
+    pc = E.PackedConv(conv.weight.detach().to(cuda), conv.bias.detach().to(cuda))
+    B, Hin, Win, h, w = 4, 37, 52, 22, 33
+    x = torch.randn(B, 256, Hin, Win).to(cuda)
+    xr = E.rec_from_f32(x)
+    coef = _coef(B, 128, 3).to(cuda)
+    y_full, r_full = pc.call_rec(xr, upsample2x=True, want_f32=True, want_rec=True, rec_coef=coef)
+    y0s, x0s = [0, 15, 6, 11], [19, 0, 7, 13]
+    y_win, r_win = pc.call_rec(xr, upsample2x=True, want_f32=True, want_rec=True, rec_coef=coef, window=(y0s, x0s, h, w))
+    rf, rw = r_full.records(), r_win.records()
+    for b in range(B):
+        ys_, xs_ = slice(2 * y0s[b], 2 * (y0s[b] + h)), slice(2 * x0s[b], 2 * (x0s[b] + w))
+        assert torch.equal(y_win[b], y_full[b, :, ys_, xs_]), f"fp32, image {b}"
+        assert torch.equal(rw[b, :, :, 1:-1, 1:-1], rf[b, :, :, 1 + ys_.start:1 + ys_.stop, 1 + xs_.start:1 + xs_.stop]), f"records, image {b}"
+    assert not rw[:, :, :, 0].any() and not rw[:, :, :, -1].any() and not rw[:, :, :, :, 0].any() and not rw[:, :, :, :, -1].any()
+    with torch.no_grad():
+        ref = conv.to(cuda)(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+    assert _rel(y_full, ref) < 5e-5
