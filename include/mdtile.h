@@ -376,11 +376,16 @@ int mdtile_vae_fast_input(const float* d_z, int N, int C, int H, int W, int tile
  *                          sequence-parallel estimator's attention, tile_utils/attn.py:55-67)
  *   mdtile_shard_selfcheck bring-up check: all-reduce, broadcast, grouped ring send / receive (a self send / receive on one rank) and
  *                          all-gather of small payloads, verified on the host; d_scratch[i] >= mdtile_shard_selfcheck_bytes(sh).
- *                          MDTILE_SHARD_TRANSPORT=rccl makes a one-device context use a 1-rank RCCL communicator (it needs none). */
+ *                          MDTILE_SHARD_TRANSPORT=rccl makes a one-device context use a 1-rank RCCL communicator (it needs none).
+ *   mdtile_shard_probe_rank  interruptible bring-up probe of a process-per-GPU communicator: the same rendezvous as mdtile_shard_init_rank on a
+ *                          NON-BLOCKING communicator, polled until it is up or `timeout_s` has passed, then aborted (ncclCommAbort) -- the calling
+ *                          thread is never left blocked inside RCCL.  Every rank calls it with the same id (an id of its own, not the one the
+ *                          real communicator will use).  MDTILE_OK: the rendezvous works, go on to mdtile_shard_init_rank. */
 typedef struct mdtile_shard mdtile_shard;
 mdtile_shard* mdtile_shard_init(int ndev, const int* dev_ids);
 int mdtile_shard_unique_id(void* id128);
 mdtile_shard* mdtile_shard_init_rank(int nranks, int rank, const void* id128, int device);
+int mdtile_shard_probe_rank(int nranks, int rank, const void* id128, int device, double timeout_s);
 void mdtile_shard_destroy(mdtile_shard* sh);
 int mdtile_shard_info(const mdtile_shard* sh, int* info4);
 mdtile_stream_t mdtile_shard_stream(const mdtile_shard* sh, int local_rank);

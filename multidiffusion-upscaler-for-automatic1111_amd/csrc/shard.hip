@@ -19,6 +19,8 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
+#include <thread>
 #include <vector>
 
 using namespace mdt;
@@ -39,6 +41,10 @@ struct Rccl {
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    // optional (NCCL >= 2.14): the interruptible bring-up probe, mdtile_shard_probe_rank
+    ncclResult_t (*CommInitRankConfig)(ncclComm_t*, int, ncclUniqueId, int, ncclConfig_t*) = nullptr;
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
 };
 
 Rccl* rccl() {
@@ -67,6 +73,9 @@ Rccl* rccl() {
     MDT_SYM(AllGather, "ncclAllGather")
     MDT_SYM(GetErrorString, "ncclGetErrorString")
 #undef MDT_SYM
+    R.CommInitRankConfig = reinterpret_cast<decltype(R.CommInitRankConfig)>(dlsym(R.h, "ncclCommInitRankConfig"));
+    R.CommGetAsyncError = reinterpret_cast<decltype(R.CommGetAsyncError)>(dlsym(R.h, "ncclCommGetAsyncError"));
+    R.CommAbort = reinterpret_cast<decltype(R.CommAbort)>(dlsym(R.h, "ncclCommAbort"));
     return &R;
 }
 
@@ -281,6 +290,49 @@ extern "C" mdtile_shard* mdtile_shard_init_rank(int nranks, int rank, const void
         return nullptr;
     }
     return sh;
+}
+
+// Interruptible bring-up probe: the rendezvous of ncclCommInitRank blocks inside RCCL for as long as a peer is missing or a link does not come
+// up, and nothing can reach a communicator that does not exist yet.  The probe makes the SAME rendezvous on a NON-BLOCKING communicator
+// (ncclCommInitRankConfig, blocking = 0), polls ncclCommGetAsyncError, and on the deadline calls ncclCommAbort -- the calling thread is
+// never left inside RCCL.  A probe that succeeds is thrown away again (the data plane keeps its blocking communicator: no ncclInProgress
+// handling in every collective); it needs an id of its own.  Returns MDTILE_OK, or MDTILE_E_HIP with the reason (timeout included).
+extern "C" int mdtile_shard_probe_rank(int nranks, int rank, const void* id128, int device, double timeout_s) {
+    Rccl* R = rccl();
+    MDT_CHECK_ARG(nranks > 0 && rank >= 0 && rank < nranks && id128 && timeout_s > 0.0, "mdtile_shard_probe_rank: bad arguments (nranks=%d rank=%d)", nranks, rank);
+    MDT_CHECK_ARG(R, "mdtile_shard_probe_rank: librccl.so not found");
+    if (!R->CommInitRankConfig || !R->CommGetAsyncError || !R->CommAbort) {
+        set_error("mdtile_shard_probe_rank: this librccl has no ncclCommInitRankConfig / ncclCommGetAsyncError / ncclCommAbort");
+        return MDTILE_E_HIP;
+    }
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    MDT_HIP(hipSetDevice(device));
+    ncclUniqueId id;
+    memcpy(&id, id128, NCCL_UNIQUE_ID_BYTES);
+    ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
+    cfg.blocking = 0;
+    ncclComm_t comm = nullptr;
+    ncclResult_t r = R->CommInitRankConfig(&comm, nranks, id, rank, &cfg);
+    const auto t0 = std::chrono::steady_clock::now();
+    bool timed_out = false;
+    while (r == ncclInProgress || (r == ncclSuccess && comm)) {
+        ncclResult_t st = ncclSuccess;
+        if (comm && R->CommGetAsyncError(comm, &st) != ncclSuccess) { r = ncclInternalError; break; }
+        r = st;
+        if (st != ncclInProgress) break;
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) { timed_out = true; break; }
+        std::this_thread::sleep_for(std::chrono::milliseconds(2));
+    }
+    int rc = MDTILE_OK;
+    if (timed_out || r != ncclSuccess) {
+        set_error(timed_out ? "mdtile_shard_probe_rank: the communicator of %d ranks did not come up within %.1f s (rank %d) -- aborted"
+                            : "mdtile_shard_probe_rank: communicator bring-up failed (nranks %d, %.1f s budget, rank %d)", nranks, timeout_s, rank);
+        rc = MDTILE_E_HIP;
+    }
+    if (comm) (void)R->CommAbort(comm);      // success or not: the probe communicator is not kept (abort = destroy without a final handshake)
+    (void)hipSetDevice(cur);
+    return rc;
 }
 
 extern "C" void mdtile_shard_destroy(mdtile_shard* sh) { shard_free(sh); }

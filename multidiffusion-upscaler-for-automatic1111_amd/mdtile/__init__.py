@@ -79,6 +79,7 @@ _SIGNATURES = {
     "mdtile_shard_init": (c_void_p, [c_int, _IP]),
     "mdtile_shard_unique_id": (c_int, [c_void_p]),
     "mdtile_shard_init_rank": (c_void_p, [c_int, c_int, c_void_p, c_int]),
+    "mdtile_shard_probe_rank": (c_int, [c_int, c_int, c_void_p, c_int, c_double]),
     "mdtile_shard_destroy": (None, [c_void_p]),
     "mdtile_shard_info": (c_int, [c_void_p, _IP]),
     "mdtile_shard_stream": (c_void_p, [c_void_p, c_int]),
@@ -999,6 +1000,14 @@ class Shard:
         buf = ctypes.create_string_buffer(128)
         _check(lib().mdtile_shard_unique_id(buf), "mdtile_shard_unique_id")
         return buf.raw
+
+    @staticmethod
+    def probe(nranks: int, rank: int, uid: bytes, device: int, timeout_s: float = 60.0) -> None:
+        """Interruptible bring-up probe (mdtile_shard_probe_rank): the rendezvous of a process-per-GPU communicator on a non-blocking
+        communicator that is aborted on the deadline and thrown away on success.  Raises MdtileError (timeout included); never leaves
+        the calling thread inside RCCL.  `uid` must be an id of its own (not the one the real communicator is built from)."""
+        buf = ctypes.create_string_buffer(bytes(uid), 128)
+        _check(lib().mdtile_shard_probe_rank(int(nranks), int(rank), buf, int(device), float(timeout_s)), "mdtile_shard_probe_rank")
 
     def _streams(self, streams):
         if streams is None:

@@ -20,6 +20,7 @@ VAE decode: tiles are dealt round-robin; the fast-mode statistics estimator (one
 from __future__ import annotations
 
 from dataclasses import dataclass
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -321,13 +322,28 @@ def init_process_context_checked(rank: int, world: int, device: int, timeout_s: 
     box = [None]
     if rank == 0:
         try:
-            box[0] = mdtile.Shard.unique_id()
+            box[0] = (mdtile.Shard.unique_id(), mdtile.Shard.unique_id())      # (probe communicator, real communicator)
         except BaseException as e:      # noqa: BLE001
             box[0] = ("error", repr(e))
     dist.broadcast_object_list(box, src=0, group=group)
     ctx, why = None, None
-    if isinstance(box[0], (bytes, bytearray)):
-        ctx, why = _run_with_timeout(lambda: mdtile.Shard(nranks=world, rank=rank, uid=bytes(box[0]), device=device), timeout_s, device)
+    ids = box[0] if isinstance(box[0], tuple) and len(box[0]) == 2 and isinstance(box[0][0], (bytes, bytearray)) else None
+    if ids is not None:
+        # 2a. the rendezvous itself, interruptibly: a NON-BLOCKING probe communicator polled under the deadline and aborted on it
+        #     (mdtile_shard_probe_rank) -- a rendezvous that cannot complete on this node is found out with no thread left inside RCCL.
+        #     (librccl without the non-blocking calls: the probe reports that and the blocking path below keeps its worker-thread seat belt.)
+        probe_ok = True
+        if dev.type == "cuda" and os.environ.get("MDTILE_SHARD_PROBE", "1") != "0":
+            _, perr = _run_with_timeout(lambda: mdtile.Shard.probe(world, rank, bytes(ids[0]), device, timeout_s=min(timeout_s, 60.0)) or True,
+                                        timeout_s + 10.0, device)
+            if perr is not None and "has no ncclCommInitRankConfig" not in perr:
+                probe_ok, why = False, f"bring-up probe: {perr}"
+        probe_ok = _vote(probe_ok, dev, group)
+        # 2b. the real (blocking) communicator, only when the probe came up on EVERY rank
+        if probe_ok:
+            ctx, why = _run_with_timeout(lambda: mdtile.Shard(nranks=world, rank=rank, uid=bytes(ids[1]), device=device), timeout_s, device)
+        elif why is None:
+            why = "bring-up probe failed on another rank"
     else:
         why = f"rank 0 could not draw an RCCL id: {box[0][1] if box[0] else 'no id'}"
     ok = _vote(ctx is not None, dev, group)

@@ -297,3 +297,42 @@ def test_bench_flow_n_ranks_on_one_device_matches_the_single_rank_image(cuda, wo
     assert d["n_gpus"] == world and d["debug_check"] is not None, d
     assert d["debug_check"]["image_shape"] == [1, 3, 2048, 2048]
     assert d["debug_check"]["assembled_image_rel_err_vs_single_rank"] < 1e-4, d["debug_check"]
+
+
+def test_bring_up_probe_is_interruptible(plugin, cuda):
+    """mdtile_shard_probe_rank: the rendezvous of ncclCommInitRank on a NON-BLOCKING communicator, polled under a deadline and aborted on it.
+    (1) a one-rank probe comes up; (2) rank 0 of a TWO-rank communicator whose peer never shows up gives up on the deadline with an error --
+    the calling thread comes back (a blocking ncclCommInitRank would sit in the rendezvous for ever: the case the round-3 review flagged,
+    bring-up worker threads left inside RCCL); (3) a regular communicator still comes up afterwards.  The probe runs in a guarded thread so
+    that a librccl that blocks anyway fails this test instead of hanging the suite."""
+    import threading
+    import time
+    E = plugin.engine
+    dev = cuda.index or 0
+
+    def guarded(fn, limit):
+        box = {}
+
+        def work():
+            torch.cuda.set_device(dev)
+            try:
+                box["value"] = fn()
+            except BaseException as e:      # noqa: BLE001
+                box["error"] = e
+        t = threading.Thread(target=work, daemon=True)
+        t0 = time.time()
+        t.start()
+        t.join(limit)
+        assert not t.is_alive(), f"the probe did not return within {limit} s"
+        return box, time.time() - t0
+
+    box, _ = guarded(lambda: E.Shard.probe(1, 0, E.Shard.unique_id(), dev, timeout_s=30.0), 60.0)
+    if "error" in box and "has no ncclCommInitRankConfig" in str(box["error"]):
+        pytest.skip("this librccl has no non-blocking bring-up calls")
+    assert "error" not in box, box.get("error")
+    box, took = guarded(lambda: E.Shard.probe(2, 0, E.Shard.unique_id(), dev, timeout_s=2.0), 60.0)
+    assert isinstance(box.get("error"), E.MdtileError) and "did not come up" in str(box["error"]), box
+    assert took < 30.0
+    sh = E.Shard(nranks=1, rank=0, uid=E.Shard.unique_id(), device=dev)      # the process can still build communicators
+    assert sh.nranks == 1
+    sh.destroy()
