@@ -97,37 +97,107 @@ struct EpiCtx {
 
 constexpr int EC_REC = 3 * 64;   // records of one constants buffer: [bias | a | s] x 1 KB (128 floats + pad for the DMA's upper lanes)
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// v <- silu(a v + s) for the 16 accumulator values of one pixel: the same arithmetic as silu_f(fmaf(v, a, s)), value by value, but
+// written stage by stage over all 16 (independent) chains and on packed fp32 pairs.  In the epilogue nothing else runs on the SIMD,
+// so what the wave does not overlap itself is lost: with the chains interleaved two at a time (what hipcc made of the per-value form)
+// every v_exp_f32 / v_rcp_f32 waited out its own latency.
+__device__ __forceinline__ void act16(f32x16& v, const f32x2 (&a)[8], const f32x2 (&s)[8]) {
+    f32x2 t[8], e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = __builtin_elementwise_fma(f32x2{v[2 * j], v[2 * j + 1]}, a[j], s[j]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = t[j] * -1.44269504088896340736f;      // __expf(-t) = exp2(t * -log2(e))
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = f32x2{__builtin_amdgcn_exp2f(e[j].x), __builtin_amdgcn_exp2f(e[j].y)};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = e[j] + 1.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = f32x2{__builtin_amdgcn_rcpf(e[j].x), __builtin_amdgcn_rcpf(e[j].y)};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        t[j] = t[j] * e[j];
+        v[2 * j] = t[j].x;
+        v[2 * j + 1] = t[j].y;
+    }
+}
+
+// 8 values -> (hi, lo) records, two values per instruction: v_cvt_pk_bf16_f32 rounds a PAIR; the pair's hi parts come back as fp32
+// with one shift and one mask; lo = bf16(v - hi) as a packed subtract and a second packed convert (2.5 VALU per value; split8r's
+// per-value form compiled to 4).
+__device__ __forceinline__ void split8p(const f32x16& v, int o, u32x4& hi, u32x4& lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x2 p = {v[o + 2 * j], v[o + 2 * j + 1]};
+        const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(p, bf16x2));
+        const f32x2 hf = {__builtin_bit_cast(float, h << 16), __builtin_bit_cast(float, h & 0xffff0000u)};
+        hi[j] = h;
+        lo[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(p - hf, bf16x2));
+    }
+}
+
+// A wave-uniform pointer the optimiser cannot see through: what is added to it afterwards stays a 32-bit lane offset next to an SGPR
+// base (LLVM otherwise re-associates base + plane + lane into (base + lane) + plane: a 64-bit VALU multiply-add per access).
+// volatile: not merged across pixel rows either (16 live SGPR pairs per tensor would spill to VGPR lanes).
+// Returned as a GLOBAL-address-space pointer (the asm hides where the value came from; a generic pointer would compile to flat_*).
+#define MDT_GLOBAL __attribute__((address_space(1)))
+typedef MDT_GLOBAL char gchar;
+__device__ __forceinline__ gchar* uniform_ptr(const void* p) {
+    size_t v = reinterpret_cast<size_t>(p);
+    asm volatile("" : "+s"(v));
+    return (gchar*)v;
+}
+__device__ __forceinline__ gchar* uniform_ptr(gchar* p) { return uniform_ptr((const void*)p); }
+// the plane of accumulator value q is (q & 3) + 8 (q >> 2): walking q = 0..15 the uniform base advances by 1, 1, 1, 5, 1, 1, 1, 5, ... planes
+#define MDT_PLANE_STEP(q) (((q) & 3) ? 1 : 5)
+
 // NPX = 1: one pixel per lane; NPX = 2: the lane owns output px (2X, 2X+1) (sub-pixel upsample kernel)
 // ECS: float4 stride between the [bias | a | s] slots of the constants buffer (64 = 1 KB slots; 32 = packed 512 B slots)
+//
+// Round 4, late: the epilogue is bound by the wave's own VALU issue, not by the memory pipe -- hipcc's code for
+// the first form spent ~100 VALU instructions per 8-value record (per-value converts, 64-bit address arithmetic per access, an
+// activation computed and then selected away when there was none, a Cout test and five SGPR-spill reloads in front of every fp32
+// store).  This form addresses every access as (wave-uniform 64-bit base) + (32-bit lane offset) -- global_* with an SGPR base --
+// so an access costs scalar adds only; the uniform bases are formed per item from an `opaque` plane size, or LLVM hoists 16 of them
+// per tensor out of the persistent loop and spills them to VGPR lanes (two v_readlane per use).
+// 32-bit lane offsets: 20 HW < 2^32 (fp32) and 32 planeO < 2^32 (records), checked on the host (rec_image_ok).
 template <int NPX, int NROW, int ECS = 64>
 __device__ __forceinline__ void epilogue_mtile(const EpiCtx& E, const u32x4* ec, f32x16 (&acc)[NROW][NPX], int mt_local, int mt_global,
                                                const int (&ys)[NROW], int x, bool x_ok) {
     // constants of this lane's 16 couts: q = 4 g + i  <->  channel 32 mt + 4 kg + 8 g + i
-    float bq[16], aq[16], sq[16];
+    f32x2 bq[8], aq[8], sq[8];
     {
         const float4* e4 = reinterpret_cast<const float4*>(ec);
         const int c4 = (mt_local * 32 + 4 * E.kg) >> 2;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 tb = E.has_bias ? e4[c4 + 2 * g] : make_float4(0.f, 0.f, 0.f, 0.f);
-            bq[4 * g] = tb.x; bq[4 * g + 1] = tb.y; bq[4 * g + 2] = tb.z; bq[4 * g + 3] = tb.w;
+            bq[2 * g] = f32x2{tb.x, tb.y}; bq[2 * g + 1] = f32x2{tb.z, tb.w};
             if (E.has_act) {
                 const float4 ta = e4[ECS + c4 + 2 * g], ts = e4[2 * ECS + c4 + 2 * g];
-                aq[4 * g] = ta.x; aq[4 * g + 1] = ta.y; aq[4 * g + 2] = ta.z; aq[4 * g + 3] = ta.w;
-                sq[4 * g] = ts.x; sq[4 * g + 1] = ts.y; sq[4 * g + 2] = ts.z; sq[4 * g + 3] = ts.w;
+                aq[2 * g] = f32x2{ta.x, ta.y}; aq[2 * g + 1] = f32x2{ta.z, ta.w};
+                sq[2 * g] = f32x2{ts.x, ts.y}; sq[2 * g + 1] = f32x2{ts.z, ts.w};
             }
         }
     }
-    const int cbase = mt_global * 32 + 4 * E.kg;
-    const size_t obase = ((size_t)E.b * E.Cout + cbase) * E.HW;
-    const int xc = x_ok ? x : 0;                                  // clamped column for the unconditional residual loads
 #pragma unroll
     for (int n = 0; n < NROW; ++n)
 #pragma unroll
         for (int e = 0; e < NPX; ++e)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) acc[n][e][q] += bq[q];
+            for (int j = 0; j < 8; ++j) {
+                acc[n][e][2 * j] += bq[j].x;
+                acc[n][e][2 * j + 1] += bq[j].y;
+            }
+    // ---- fp32 tensors (residual in, y32 out): plane of value q = uniform base + ((q&3) + 8 (q>>2)) HW; lane = 4 kg HW + y W + x
+    const size_t HW4 = E.HW * sizeof(float);
+    const size_t slab = ((size_t)E.b * E.Cout + (size_t)mt_global * 32) * HW4;
+    const int xc = x_ok ? x : 0;                                  // clamped column for the unconditional residual loads
+    const unsigned lane32 = ((unsigned)(4 * E.kg) * (unsigned)E.HW + (unsigned)xc) * 4u;
     if (E.res) {
+        const char* rb = reinterpret_cast<const char*>(E.res) + slab;
         constexpr int RB = NPX == 1 ? 2 : 1;      // rows whose residual is in flight together (32 registers)
 #pragma unroll
         for (int n0 = 0; n0 < NROW; n0 += RB) {
@@ -135,16 +205,18 @@ __device__ __forceinline__ void epilogue_mtile(const EpiCtx& E, const u32x4* ec,
 #pragma unroll
             for (int n = 0; n < RB; ++n) {
                 const int yc = ys[n0 + n] < E.H ? ys[n0 + n] : E.H - 1;
-                const float* rp0 = E.res + obase + (size_t)yc * E.W + xc;
+                const unsigned ro = lane32 + (unsigned)(yc * E.W) * 4u;
+                gchar* up = uniform_ptr(rb);
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
-                    const float* rp = rp0 + (size_t)((q & 3) + 8 * (q >> 2)) * E.HW;
+                    if (q) up = uniform_ptr(up + MDT_PLANE_STEP(q) * HW4);
+                    gchar* rp = up + (size_t)ro;
                     if (NPX == 2) {
-                        const float2 r2 = *reinterpret_cast<const float2*>(rp);
+                        const f32x2 r2 = *(const MDT_GLOBAL f32x2*)rp;
                         r[n][0][q] = r2.x;
                         r[n][NPX - 1][q] = r2.y;
                     } else {
-                        r[n][0][q] = *rp;
+                        r[n][0][q] = *(const MDT_GLOBAL float*)rp;
                     }
                 }
             }
@@ -156,49 +228,72 @@ __device__ __forceinline__ void epilogue_mtile(const EpiCtx& E, const u32x4* ec,
                     for (int q = 0; q < 16; ++q) acc[n0 + n][e][q] += r[n][e][q];
         }
     }
+    // ---- record image: plane ((mt*2 + R)*2 + kg) of the hi half, the lo half Cout/8 planes further; lane = kg plane + row + column
+    const int Pn = E.Cout >> 3;
+    const size_t pl16 = E.planeO * sizeof(u32x4);
+    char* const yr = reinterpret_cast<char*>(E.yrec) + ((size_t)E.b * 2 * Pn + (size_t)mt_global * 4) * pl16;
+    const size_t lo_half = (size_t)Pn * pl16;
+    const unsigned rlane = ((unsigned)E.kg * (unsigned)E.planeO + (unsigned)(xc + mdt::REC_COL0)) * 16u;      // padded column 0 of ... + x
+    char* const yb32 = reinterpret_cast<char*>(E.y32) + slab;
+    const bool whole = mt_global * 32 + 32 <= E.Cout;             // narrow convs (conv_out: 3 couts): couts past Cout are padding
 #pragma unroll
     for (int n = 0; n < NROW; ++n) {
         const int y = ys[n];
         if (!(y < E.H && x_ok)) continue;
-        const size_t o0 = obase + (size_t)y * E.W + x;
         if (E.y32) {
+            const unsigned ro = lane32 + (unsigned)(y * E.W) * 4u;
+            if (whole) {
+                gchar* up = uniform_ptr(yb32);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                if (cbase + (q & 3) + 8 * (q >> 2) >= E.Cout) continue;          // narrow convs: couts past Cout are padding
-                float* yp = E.y32 + o0 + (size_t)((q & 3) + 8 * (q >> 2)) * E.HW;
-                if (NPX == 2) *reinterpret_cast<float2*>(yp) = make_float2(acc[n][0][q], acc[n][NPX - 1][q]);
-                else *yp = acc[n][0][q];
+                for (int q = 0; q < 16; ++q) {
+                    if (q) up = uniform_ptr(up + MDT_PLANE_STEP(q) * HW4);
+                    gchar* yp = up + (size_t)ro;
+                    if (NPX == 2) *(MDT_GLOBAL f32x2*)yp = f32x2{acc[n][0][q], acc[n][NPX - 1][q]};
+                    else *(MDT_GLOBAL float*)yp = acc[n][0][q];
+                }
+            } else {
+                const int cbase = mt_global * 32 + 4 * E.kg;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    if (cbase + (q & 3) + 8 * (q >> 2) >= E.Cout) continue;
+                    char* yp = yb32 + (size_t)((q & 3) + 8 * (q >> 2)) * HW4 + (size_t)ro;
+                    if (NPX == 2) *reinterpret_cast<float2*>(yp) = make_float2(acc[n][0][q], acc[n][NPX - 1][q]);
+                    else *reinterpret_cast<float*>(yp) = acc[n][0][q];
+                }
             }
         }
         if (E.yrec) {
-            // records R = 0 (q 0..7) and R = 1 (q 8..15) of this lane: planes ((mt*2 + R)*2 + kg)
-            const int Pn = E.Cout >> 3;
-            u32x4* yb = E.yrec + (size_t)E.b * 2 * Pn * E.planeO;
+            if (E.has_act) {
+#pragma unroll
+                for (int e = 0; e < NPX; ++e) act16(acc[n][e], aq, sq);
+            }
+            const unsigned rrow = rlane + (unsigned)((y + 1) * E.WpO) * 16u;      // record (row y + 1, padded column x) of plane kg
 #pragma unroll
             for (int R = 0; R < 2; ++R) {
-                const size_t pl = (size_t)((mt_global * 2 + R) * 2 + E.kg) * E.planeO;
+                gchar* const yp = uniform_ptr(yr + (size_t)(2 * R) * pl16), *const ypl = uniform_ptr(yp + lo_half);
 #pragma unroll
                 for (int e = 0; e < NPX; ++e) {
-                    float t8[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float t = acc[n][e][8 * R + j];
-                        t8[j] = E.has_act ? silu_f(fmaf(t, aq[8 * R + j], sq[8 * R + j])) : t;
-                    }
                     u32x4 hi, lo;
-                    split8r(t8, hi, lo);
-                    const size_t at = pl + (size_t)(y + 1) * E.WpO + (x + e + 1 + mdt::REC_COL0);
-                    yb[at] = hi;
-                    yb[(size_t)Pn * E.planeO + at] = lo;
+                    split8p(acc[n][e], 8 * R, hi, lo);
+                    const size_t at = (size_t)(rrow + (unsigned)(e + 1) * 16u);
+                    *(MDT_GLOBAL u32x4*)(yp + at) = hi;
+                    *(MDT_GLOBAL u32x4*)(ypl + at) = lo;
                 }
-                // zero border of the record image (this block owns the border cells next to its edge pixels)
-                const bool left = x == 0, right = x + NPX == E.W, top = y == 0, bot = y == E.H - 1;
-                if (left || right || top || bot) {
-                    const u32x4 z = {0u, 0u, 0u, 0u};
-                    auto zrec = [&](int py, int px) {
-                        const size_t at = pl + (size_t)py * E.WpO + px + mdt::REC_COL0;      // (px: padded column, 0 = left border)
-                        yb[at] = z;
-                        yb[(size_t)Pn * E.planeO + at] = z;
+            }
+            // zero border of the record image (this block owns the border cells next to its edge pixels)
+            const bool left = x == 0, right = x + NPX == E.W, top = y == 0, bot = y == E.H - 1;
+            if (left || right || top || bot) {
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                unsigned kgb = (unsigned)E.kg;
+                asm volatile("" : "+v"(kgb));      // formed here, on the rare path: hoisted out of the persistent loop these offsets cost registers (scratch)
+                const unsigned p0 = (kgb * (unsigned)E.planeO + (unsigned)mdt::REC_COL0) * 16u;
+#pragma unroll
+                for (int R = 0; R < 2; ++R) {
+                    char* const yp = yr + (size_t)(2 * R) * pl16;
+                    auto zrec = [&](int py, int px) {      // (px: padded column, 0 = left border)
+                        const size_t at = (size_t)(p0 + (unsigned)(py * E.WpO + px) * 16u);
+                        *reinterpret_cast<u32x4*>(yp + at) = z;
+                        *reinterpret_cast<u32x4*>(yp + lo_half + at) = z;
                     };
                     if (left) zrec(y + 1, 0);
                     if (right) zrec(y + 1, E.W + 1);

@@ -334,7 +334,8 @@ extern "C" size_t mdtile_rec_size(int B, int C, int H, int W) {
 }
 
 static bool rec_image_ok(int B, int C, int H, int W) {
-    // per-lane DMA offsets are 32-bit BYTE offsets inside one pair of planes; record indices of a whole image stay below 2^32
+    // per-lane DMA offsets are 32-bit BYTE offsets inside one pair of planes; record indices of a whole image stay below 2^32.
+    // The epilogue (conv_rec_common.h) adds 32-bit lane offsets to wave-uniform bases: < 2 record planes, < 5 fp32 planes (HW <= plane records)
     return B > 0 && C > 0 && C % 32 == 0 && H > 0 && W > 0 && H + 2 <= 65535 && (size_t)B * (C / 8) <= 65535 &&
            2 * rec_plane_records(H, W) * 16 < ((size_t)1 << 32);
 }

@@ -50,6 +50,20 @@ struct WorkItem {
 // the NEXT item (weight chunks 0 and 1, input tile of K-step 0) are DMA'd behind the LAST barrier of the current item's K loop
 // -- their LDS slots are free by then -- so neither the launch gap nor the prologue's HBM round trip shows between items:
 // they run under the last MFMAs and the epilogue.
+// Start-up stagger of the persistent blocks (ConvRParams::skew_ticks = the spread in 100 MHz ticks; 0 = off).  Every block runs items of
+// ONE duration, so the whole chip moves in lock step: all 256 CUs spend the K loop without touching HBM and then all write (and, for a
+// conv2, read) their epilogue at once -- 64 MB per tensor and round, served at the HBM rate while the matrix cores idle (round 4:
+// probes/conv_item_timeline.py).  A block that starts `d` late stays `d` late for the whole launch: with the
+// delays spread over an item period the epilogue bursts of the CUs fall under the K loops of the others.  Price: the last block ends a
+// spread later -- the launcher staggers only launches of many rounds.  Wave 0 sleeps; the other waves wait at the first barrier.
+__device__ __forceinline__ void stagger_start(const ConvRParams& P, int wave) {
+    if (wave != 0 || P.skew_ticks == 0) return;
+    const unsigned frac = (blockIdx.x * 0x9E3779B1u) >> 24;                    // 0 .. 255, scattered over the block indices (XCDs, CUs)
+    const unsigned long long d = ((unsigned long long)P.skew_ticks * frac) >> 8;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < d) __builtin_amdgcn_s_sleep(32);
+}
+
 template <int MW, int WM, int NROW>
 __global__ __launch_bounds__(512, 2) void k_conv3x3_rec(const ConvRParams P) {
     constexpr int WR = 8 / WM, TH = WR * NROW, MT = MW * WM, HN = NROW / 2;
@@ -162,6 +176,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rec(const ConvRParams P) {
     issue_weights(cur, 0, 0);
     issue_weights(cur, 1, 1);
     issue_consts(cur, 0);
+    stagger_start(P, wave);
     const int nph = P.NK * 3;
     int par = 0;
 
@@ -394,6 +409,7 @@ __global__ __launch_bounds__(512, 2) void k_upconv_rec(const ConvRParams P) {
     issue_weights(cur, 0, 0);
     issue_weights(cur, 1, 1);
     issue_consts(cur, 0);
+    stagger_start(P, wave);
     int par = 0, r0 = 0;       // constants-buffer parity, ring slot of this item's chunk 0
 
     while (true) {
@@ -560,6 +576,8 @@ namespace mdt {
 size_t conv_bf16x3_direct_records(int cout, int cin);   // vae_conv_bf16x3.hip
 
 // MDTILE_REC_PERSIST=0: one item per block (A/B of the persistent schedule; read per launch so a probe can flip it in-process)
+constexpr int REC_STAGGER_PCT_DEFAULT = 0;      // (set from the A/B: profiles/r4u)
+
 static bool rec_persistent() {
     const char* e = getenv("MDTILE_REC_PERSIST");
     return !(e && e[0] == '0');
@@ -654,11 +672,18 @@ int conv_rec_launch(const void* d_xrec, const void* d_w_rec, const float* d_bias
         const long long items8 = (px * ((hin + (up ? 3 : 7)) / (up ? 4 : 8)) + 7) / 8 * 8 * per * B;
         if (rec_two_blocks(items16, items8, cus, up)) return conv_rec2_launch(P, B, up, s, num_cus());
     }
+    // start-up stagger (stagger_start): spread = MDTILE_REC_STAGGER_PCT percent of an estimated item period, launches of >= 6 rounds only
+    auto stagger = [&](long long items, int cus, unsigned period_ticks) {
+        const char* e = getenv("MDTILE_REC_STAGGER_PCT");      // (read per launch: probes/conv_stagger_ab.py switches it between launches)
+        const int p = e ? atoi(e) : REC_STAGGER_PCT_DEFAULT;
+        P.skew_ticks = (rec_persistent() && items >= 6LL * cus && p > 0) ? period_ticks * (unsigned)p / 100u : 0u;
+    };
     if (up) {
         P.PX = (P.Win + 31) / 32;
         P.ptiles = P.PX * ((P.Hin + 7) / 8);
         const long long items = (long long)((P.ptiles + 7) / 8) * 8 * P.NCB * 2 * B;
         const int cus = num_cus();
+        stagger(items, cus, (unsigned)P.NK * 400u + 2000u);
         dim3 grid((unsigned)((items < cus || !rec_persistent()) ? items : cus / 8 * 8)), block(512);
         hipLaunchKernelGGL(k_upconv_rec, grid, block, 0, s, P);
         MDT_LAUNCH_CHECK();
@@ -668,6 +693,7 @@ int conv_rec_launch(const void* d_xrec, const void* d_w_rec, const float* d_bias
     P.ptiles = P.PX * ((H + 15) / 16);
     const long long items = (long long)((P.ptiles + 7) / 8) * 8 * P.NCB * B;
     const int cus = num_cus();                    // one block per CU (155 KB LDS, 2 waves per SIMD)
+    if (cout % 128 == 0) stagger(items, cus, (unsigned)P.NK * 900u + 1500u);
     dim3 grid((unsigned)((items < cus || !rec_persistent()) ? items : cus / 8 * 8)), block(512);
     if (cout % 128 == 0) hipLaunchKernelGGL((k_conv3x3_rec<2, 2, 4>), grid, block, 0, s, P);
     else hipLaunchKernelGGL((k_conv3x3_rec<1, 1, 2>), grid, block, 0, s, P);      // conv_out: one 32-cout tile, bias padded to 32 by the caller
