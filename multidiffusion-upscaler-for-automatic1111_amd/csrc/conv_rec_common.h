@@ -93,6 +93,7 @@ struct EpiCtx {
     int b, kg;
     size_t HW, planeO;   // fp32 plane, record plane ((H + 2) * rec_pitch(W))
     int WpO;
+    int dbg;             // probing (ConvRParams::dbg): bit 4 = the fp32 stores are skipped, bit 5 = the record stores are skipped (probes/conv_item_timeline.py --dbg)
 };
 
 constexpr int EC_REC = 3 * 64;   // records of one constants buffer: [bias | a | s] x 1 KB (128 floats + pad for the DMA's upper lanes)
@@ -100,27 +101,27 @@ constexpr int EC_REC = 3 * 64;   // records of one constants buffer: [bias | a |
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
-// v <- silu(a v + s) for the 16 accumulator values of one pixel: the same arithmetic as silu_f(fmaf(v, a, s)), value by value, but
-// written stage by stage over all 16 (independent) chains and on packed fp32 pairs.  In the epilogue nothing else runs on the SIMD,
+// v <- silu(a v + s) for 8 of the 16 accumulator values of one pixel (one record's worth: o = 0 or 8): the same arithmetic as silu_f(fmaf(v, a, s)), value by value, but
+// written stage by stage over its 8 (independent) chains and on packed fp32 pairs.  In the epilogue nothing else runs on the SIMD,
 // so what the wave does not overlap itself is lost: with the chains interleaved two at a time (what hipcc made of the per-value form)
 // every v_exp_f32 / v_rcp_f32 waited out its own latency.
-__device__ __forceinline__ void act16(f32x16& v, const f32x2 (&a)[8], const f32x2 (&s)[8]) {
-    f32x2 t[8], e[8];
+__device__ __forceinline__ void act8(f32x16& v, int o, const f32x2 (&a)[4], const f32x2 (&s)[4]) {
+    f32x2 t[4], e[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) t[j] = __builtin_elementwise_fma(f32x2{v[2 * j], v[2 * j + 1]}, a[j], s[j]);
+    for (int j = 0; j < 4; ++j) t[j] = __builtin_elementwise_fma(f32x2{v[o + 2 * j], v[o + 2 * j + 1]}, a[j], s[j]);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) e[j] = t[j] * -1.44269504088896340736f;      // __expf(-t) = exp2(t * -log2(e))
+    for (int j = 0; j < 4; ++j) e[j] = t[j] * -1.44269504088896340736f;      // __expf(-t) = exp2(t * -log2(e))
 #pragma unroll
-    for (int j = 0; j < 8; ++j) e[j] = f32x2{__builtin_amdgcn_exp2f(e[j].x), __builtin_amdgcn_exp2f(e[j].y)};
+    for (int j = 0; j < 4; ++j) e[j] = f32x2{__builtin_amdgcn_exp2f(e[j].x), __builtin_amdgcn_exp2f(e[j].y)};
 #pragma unroll
-    for (int j = 0; j < 8; ++j) e[j] = e[j] + 1.0f;
+    for (int j = 0; j < 4; ++j) e[j] = e[j] + 1.0f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) e[j] = f32x2{__builtin_amdgcn_rcpf(e[j].x), __builtin_amdgcn_rcpf(e[j].y)};
+    for (int j = 0; j < 4; ++j) e[j] = f32x2{__builtin_amdgcn_rcpf(e[j].x), __builtin_amdgcn_rcpf(e[j].y)};
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < 4; ++j) {
         t[j] = t[j] * e[j];
-        v[2 * j] = t[j].x;
-        v[2 * j + 1] = t[j].y;
+        v[o + 2 * j] = t[j].x;
+        v[o + 2 * j + 1] = t[j].y;
     }
 }
 
@@ -163,151 +164,171 @@ __device__ __forceinline__ gchar* uniform_ptr(gchar* p) { return uniform_ptr((co
 // so an access costs scalar adds only; the uniform bases are formed per item from an `opaque` plane size, or LLVM hoists 16 of them
 // per tensor out of the persistent loop and spills them to VGPR lanes (two v_readlane per use).
 // 32-bit lane offsets: 20 HW < 2^32 (fp32) and 32 planeO < 2^32 (records), checked on the host (rec_image_ok).
-template <int NPX, int NROW, int ECS = 64>
-__device__ __forceinline__ void epilogue_mtile(const EpiCtx& E, const u32x4* ec, f32x16 (&acc)[NROW][NPX], int mt_local, int mt_global,
-                                               const int (&ys)[NROW], int x, bool x_ok) {
-    // constants of this lane's 16 couts: q = 4 g + i  <->  channel 32 mt + 4 kg + 8 g + i
-    f32x2 bq[8], aq[8], sq[8];
-    {
-        const float4* e4 = reinterpret_cast<const float4*>(ec);
-        const int c4 = (mt_local * 32 + 4 * E.kg) >> 2;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 tb = E.has_bias ? e4[c4 + 2 * g] : make_float4(0.f, 0.f, 0.f, 0.f);
-            bq[2 * g] = f32x2{tb.x, tb.y}; bq[2 * g + 1] = f32x2{tb.z, tb.w};
-            if (E.has_act) {
-                const float4 ta = e4[ECS + c4 + 2 * g], ts = e4[2 * ECS + c4 + 2 * g];
-                aq[2 * g] = f32x2{ta.x, ta.y}; aq[2 * g + 1] = f32x2{ta.z, ta.w};
-                sq[2 * g] = f32x2{ts.x, ts.y}; sq[2 * g + 1] = f32x2{ts.z, ts.w};
-            }
-        }
-    }
-#pragma unroll
-    for (int n = 0; n < NROW; ++n)
-#pragma unroll
-        for (int e = 0; e < NPX; ++e)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                acc[n][e][2 * j] += bq[j].x;
-                acc[n][e][2 * j + 1] += bq[j].y;
-            }
-    // ---- fp32 tensors (residual in, y32 out): plane of value q = uniform base + ((q&3) + 8 (q>>2)) HW; lane = 4 kg HW + y W + x
+template <int NPX, int NROW, int MW, int ECS = 64>
+__device__ __forceinline__ void epilogue_item(const EpiCtx& E, const u32x4* ec, f32x16 (&acc)[MW][NROW][NPX], int mt_local0, int mt_global0,
+                                              const int (&ys)[NROW], int x, bool x_ok) {
+    // The wave's MW 32-cout tiles are walked in UNITS of RB pixel rows (one residual round trip each: 32 values per lane).  The residual of
+    // unit u + 1 is requested before unit u is added, stored and activated, so that its HBM round trip (3-6 k cycles; four of them used to
+    // be exposed per conv2 item) runs under that work.  One extra 32-register buffer: possible since the accesses are SGPR-based (a
+    // 64-bit vector address per load had cost 64 more).
+    constexpr int RB = NPX == 1 ? 2 : 1, UPM = NROW / RB, NU = MW * UPM;
     const size_t HW4 = E.HW * sizeof(float);
-    const size_t slab = ((size_t)E.b * E.Cout + (size_t)mt_global * 32) * HW4;
     const int xc = x_ok ? x : 0;                                  // clamped column for the unconditional residual loads
-    const unsigned lane32 = ((unsigned)(4 * E.kg) * (unsigned)E.HW + (unsigned)xc) * 4u;
-    if (E.res) {
-        const char* rb = reinterpret_cast<const char*>(E.res) + slab;
-        constexpr int RB = NPX == 1 ? 2 : 1;      // rows whose residual is in flight together (32 registers)
+    unsigned kgo = (unsigned)E.kg;
+    asm volatile("" : "+v"(kgo));      // what hangs on the lane's half (kg) is formed per item: as loop invariants these offsets end up in scratch
+    const unsigned lane32 = ((4u * kgo) * (unsigned)E.HW + (unsigned)xc) * 4u;
+    const int Pn = E.Cout >> 3;
+    const size_t pl16 = E.planeO * sizeof(u32x4);
+    const size_t lo_half = (size_t)Pn * pl16;
+    const unsigned rlane = (kgo * (unsigned)E.planeO + (unsigned)(xc + mdt::REC_COL0)) * 16u;      // padded column 0 of ... + x
+
+    constexpr bool AHEAD = NPX == 1;      // (the sub-pixel kernel holds two pixels per lane and is never given a residual by the decoder: plain form there)
+    float rbuf[AHEAD ? 2 : 1][RB][NPX][16];
+    auto request_residual = [&](int u, float (&r)[RB][NPX][16]) {
+        const int m = u / UPM, n0 = (u % UPM) * RB;
+        const char* rb = reinterpret_cast<const char*>(E.res) + ((size_t)E.b * E.Cout + (size_t)(mt_global0 + m) * 32) * HW4;
 #pragma unroll
-        for (int n0 = 0; n0 < NROW; n0 += RB) {
-            float r[RB][NPX][16];
+        for (int n = 0; n < RB; ++n) {
+            const int yc = ys[n0 + n] < E.H ? ys[n0 + n] : E.H - 1;
+            const unsigned ro = lane32 + (unsigned)(yc * E.W) * 4u;
+            gchar* up = uniform_ptr(rb);
 #pragma unroll
-            for (int n = 0; n < RB; ++n) {
-                const int yc = ys[n0 + n] < E.H ? ys[n0 + n] : E.H - 1;
-                const unsigned ro = lane32 + (unsigned)(yc * E.W) * 4u;
-                gchar* up = uniform_ptr(rb);
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    if (q) up = uniform_ptr(up + MDT_PLANE_STEP(q) * HW4);
-                    gchar* rp = up + (size_t)ro;
-                    if (NPX == 2) {
-                        const f32x2 r2 = *(const MDT_GLOBAL f32x2*)rp;
-                        r[n][0][q] = r2.x;
-                        r[n][NPX - 1][q] = r2.y;
-                    } else {
-                        r[n][0][q] = *(const MDT_GLOBAL float*)rp;
-                    }
+            for (int q = 0; q < 16; ++q) {
+                if (q) up = uniform_ptr(up + MDT_PLANE_STEP(q) * HW4);
+                gchar* rp = up + (size_t)ro;
+                if (NPX == 2) {
+                    const f32x2 r2 = *(const MDT_GLOBAL f32x2*)rp;
+                    r[n][0][q] = r2.x;
+                    r[n][NPX - 1][q] = r2.y;
+                } else {
+                    r[n][0][q] = *(const MDT_GLOBAL float*)rp;
                 }
             }
+        }
+    };
+    if (AHEAD && E.res) request_residual(0, rbuf[0]);
+
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int m = u / UPM, n0 = (u % UPM) * RB;
+        const int mt_global = mt_global0 + m;
+        // constants of this lane's 16 couts of tile m: q = 4 g + i  <->  channel 32 mt + 4 kg + 8 g + i; read from LDS where they are
+        // used (bias: once per tile; (a, s): per pixel row) -- kept in registers across a unit they were the first thing hipcc spilled
+        const float4* e4 = reinterpret_cast<const float4*>(ec) + ((mt_local0 + m) * 8 + kgo);
+        if (u % UPM == 0 && E.has_bias) {
+            f32x2 bq[8];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 tb = e4[2 * g];
+                bq[2 * g] = f32x2{tb.x, tb.y}; bq[2 * g + 1] = f32x2{tb.z, tb.w};
+            }
+#pragma unroll
+            for (int n = 0; n < NROW; ++n)
+#pragma unroll
+                for (int e = 0; e < NPX; ++e)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        acc[m][n][e][2 * j] += bq[j].x;
+                        acc[m][n][e][2 * j + 1] += bq[j].y;
+                    }
+        }
+        if (E.res) {
+            if (!AHEAD) request_residual(u, rbuf[0]);
+            else if (u + 1 < NU) request_residual(u + 1, rbuf[(u + 1) & 1]);
 #pragma unroll
             for (int n = 0; n < RB; ++n)
 #pragma unroll
                 for (int e = 0; e < NPX; ++e)
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) acc[n0 + n][e][q] += r[n][e][q];
+                    for (int q = 0; q < 16; ++q) acc[m][n0 + n][e][q] += rbuf[AHEAD ? (u & 1) : 0][n][e][q];
         }
-    }
-    // ---- record image: plane ((mt*2 + R)*2 + kg) of the hi half, the lo half Cout/8 planes further; lane = kg plane + row + column
-    const int Pn = E.Cout >> 3;
-    const size_t pl16 = E.planeO * sizeof(u32x4);
-    char* const yr = reinterpret_cast<char*>(E.yrec) + ((size_t)E.b * 2 * Pn + (size_t)mt_global * 4) * pl16;
-    const size_t lo_half = (size_t)Pn * pl16;
-    const unsigned rlane = ((unsigned)E.kg * (unsigned)E.planeO + (unsigned)(xc + mdt::REC_COL0)) * 16u;      // padded column 0 of ... + x
-    char* const yb32 = reinterpret_cast<char*>(E.y32) + slab;
-    const bool whole = mt_global * 32 + 32 <= E.Cout;             // narrow convs (conv_out: 3 couts): couts past Cout are padding
+        // ---- fp32 tensor: plane of value q = uniform base + ((q&3) + 8 (q>>2)) HW; lane = 4 kg HW + y W + x
+        // ---- record image: plane ((mt*2 + R)*2 + kg) of the hi half, the lo half Cout/8 planes further; lane = kg plane + row + column
+        const size_t slab = ((size_t)E.b * E.Cout + (size_t)mt_global * 32) * HW4;
+        char* const yb32 = reinterpret_cast<char*>(E.y32) + slab;
+        char* const yr = reinterpret_cast<char*>(E.yrec) + ((size_t)E.b * 2 * Pn + (size_t)mt_global * 4) * pl16;
+        const bool whole = MW > 1 || mt_global * 32 + 32 <= E.Cout;   // narrow convs (conv_out: 3 couts; the one-tile-per-wave kernel only): couts past Cout are padding
 #pragma unroll
-    for (int n = 0; n < NROW; ++n) {
-        const int y = ys[n];
-        if (!(y < E.H && x_ok)) continue;
-        if (E.y32) {
-            const unsigned ro = lane32 + (unsigned)(y * E.W) * 4u;
-            if (whole) {
-                gchar* up = uniform_ptr(yb32);
+        for (int nn = 0; nn < RB; ++nn) {
+            const int n = n0 + nn;
+            const int y = ys[n];
+            if (!(y < E.H && x_ok)) continue;
+            if (E.y32 && !(E.dbg & 16)) {
+                const unsigned ro = lane32 + (unsigned)(y * E.W) * 4u;
+                if (whole) {
+                    gchar* up = uniform_ptr(yb32);
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    if (q) up = uniform_ptr(up + MDT_PLANE_STEP(q) * HW4);
-                    gchar* yp = up + (size_t)ro;
-                    if (NPX == 2) *(MDT_GLOBAL f32x2*)yp = f32x2{acc[n][0][q], acc[n][NPX - 1][q]};
-                    else *(MDT_GLOBAL float*)yp = acc[n][0][q];
-                }
-            } else {
-                const int cbase = mt_global * 32 + 4 * E.kg;
+                    for (int q = 0; q < 16; ++q) {
+                        if (q) up = uniform_ptr(up + MDT_PLANE_STEP(q) * HW4);
+                        gchar* yp = up + (size_t)ro;
+                        if (NPX == 2) *(MDT_GLOBAL f32x2*)yp = f32x2{acc[m][n][0][q], acc[m][n][NPX - 1][q]};
+                        else *(MDT_GLOBAL float*)yp = acc[m][n][0][q];
+                    }
+                } else {
+                    const int cbase = mt_global * 32 + 4 * E.kg;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    if (cbase + (q & 3) + 8 * (q >> 2) >= E.Cout) continue;
-                    char* yp = yb32 + (size_t)((q & 3) + 8 * (q >> 2)) * HW4 + (size_t)ro;
-                    if (NPX == 2) *reinterpret_cast<float2*>(yp) = make_float2(acc[n][0][q], acc[n][NPX - 1][q]);
-                    else *reinterpret_cast<float*>(yp) = acc[n][0][q];
-                }
-            }
-        }
-        if (E.yrec) {
-            if (E.has_act) {
-#pragma unroll
-                for (int e = 0; e < NPX; ++e) act16(acc[n][e], aq, sq);
-            }
-            const unsigned rrow = rlane + (unsigned)((y + 1) * E.WpO) * 16u;      // record (row y + 1, padded column x) of plane kg
-#pragma unroll
-            for (int R = 0; R < 2; ++R) {
-                gchar* const yp = uniform_ptr(yr + (size_t)(2 * R) * pl16), *const ypl = uniform_ptr(yp + lo_half);
-#pragma unroll
-                for (int e = 0; e < NPX; ++e) {
-                    u32x4 hi, lo;
-                    split8p(acc[n][e], 8 * R, hi, lo);
-                    const size_t at = (size_t)(rrow + (unsigned)(e + 1) * 16u);
-                    *(MDT_GLOBAL u32x4*)(yp + at) = hi;
-                    *(MDT_GLOBAL u32x4*)(ypl + at) = lo;
+                    for (int q = 0; q < 16; ++q) {
+                        if (cbase + (q & 3) + 8 * (q >> 2) >= E.Cout) continue;
+                        char* yp = yb32 + (size_t)((q & 3) + 8 * (q >> 2)) * HW4 + (size_t)ro;
+                        if (NPX == 2) *reinterpret_cast<float2*>(yp) = make_float2(acc[m][n][0][q], acc[m][n][NPX - 1][q]);
+                        else *reinterpret_cast<float*>(yp) = acc[m][n][0][q];
+                    }
                 }
             }
-            // zero border of the record image (this block owns the border cells next to its edge pixels)
-            const bool left = x == 0, right = x + NPX == E.W, top = y == 0, bot = y == E.H - 1;
-            if (left || right || top || bot) {
-                const u32x4 z = {0u, 0u, 0u, 0u};
-                unsigned kgb = (unsigned)E.kg;
-                asm volatile("" : "+v"(kgb));      // formed here, on the rare path: hoisted out of the persistent loop these offsets cost registers (scratch)
-                const unsigned p0 = (kgb * (unsigned)E.planeO + (unsigned)mdt::REC_COL0) * 16u;
+            if (E.yrec) {
+                const unsigned rrow = rlane + (unsigned)((y + 1) * E.WpO) * 16u;      // record (row y + 1, padded column x) of plane kg
 #pragma unroll
                 for (int R = 0; R < 2; ++R) {
-                    char* const yp = yr + (size_t)(2 * R) * pl16;
-                    auto zrec = [&](int py, int px) {      // (px: padded column, 0 = left border)
-                        const size_t at = (size_t)(p0 + (unsigned)(py * E.WpO + px) * 16u);
-                        *reinterpret_cast<u32x4*>(yp + at) = z;
-                        *reinterpret_cast<u32x4*>(yp + lo_half + at) = z;
-                    };
-                    if (left) zrec(y + 1, 0);
-                    if (right) zrec(y + 1, E.W + 1);
-                    if (top) {
+                    if (E.has_act) {
+                        f32x2 aq[4], sq[4];
 #pragma unroll
-                        for (int e = 0; e < NPX; ++e) zrec(0, x + e + 1);
-                        if (left) zrec(0, 0);
-                        if (right) zrec(0, E.W + 1);
+                        for (int g = 0; g < 2; ++g) {
+                            const float4 ta = e4[ECS + 4 * R + 2 * g], ts = e4[2 * ECS + 4 * R + 2 * g];
+                            aq[2 * g] = f32x2{ta.x, ta.y}; aq[2 * g + 1] = f32x2{ta.z, ta.w};
+                            sq[2 * g] = f32x2{ts.x, ts.y}; sq[2 * g + 1] = f32x2{ts.z, ts.w};
+                        }
+#pragma unroll
+                        for (int e = 0; e < NPX; ++e) act8(acc[m][n][e], 8 * R, aq, sq);
                     }
-                    if (bot) {
+                    gchar* const yp = uniform_ptr(yr + (size_t)(2 * R) * pl16), *const ypl = uniform_ptr(yp + lo_half);
 #pragma unroll
-                        for (int e = 0; e < NPX; ++e) zrec(E.H + 1, x + e + 1);
-                        if (left) zrec(E.H + 1, 0);
-                        if (right) zrec(E.H + 1, E.W + 1);
+                    for (int e = 0; e < NPX; ++e) {
+                        u32x4 hi, lo;
+                        split8p(acc[m][n][e], 8 * R, hi, lo);
+                        const size_t at = (size_t)(rrow + (unsigned)(e + 1) * 16u);
+                        if (!(E.dbg & 32)) {
+                            *(MDT_GLOBAL u32x4*)(yp + at) = hi;
+                            *(MDT_GLOBAL u32x4*)(ypl + at) = lo;
+                        }
+                    }
+                }
+                // zero border of the record image (this block owns the border cells next to its edge pixels)
+                const bool left = x == 0, right = x + NPX == E.W, top = y == 0, bot = y == E.H - 1;
+                if (left || right || top || bot) {
+                    const u32x4 z = {0u, 0u, 0u, 0u};
+                    const unsigned p0 = (kgo * (unsigned)E.planeO + (unsigned)mdt::REC_COL0) * 16u;
+#pragma unroll
+                    for (int R = 0; R < 2; ++R) {
+                        char* const yp = yr + (size_t)(2 * R) * pl16;
+                        auto zrec = [&](int py, int px) {      // (px: padded column, 0 = left border)
+                            const size_t at = (size_t)(p0 + (unsigned)(py * E.WpO + px) * 16u);
+                            *reinterpret_cast<u32x4*>(yp + at) = z;
+                            *reinterpret_cast<u32x4*>(yp + lo_half + at) = z;
+                        };
+                        if (left) zrec(y + 1, 0);
+                        if (right) zrec(y + 1, E.W + 1);
+                        if (top) {
+#pragma unroll
+                            for (int e = 0; e < NPX; ++e) zrec(0, x + e + 1);
+                            if (left) zrec(0, 0);
+                            if (right) zrec(0, E.W + 1);
+                        }
+                        if (bot) {
+#pragma unroll
+                            for (int e = 0; e < NPX; ++e) zrec(E.H + 1, x + e + 1);
+                            if (left) zrec(E.H + 1, 0);
+                            if (right) zrec(E.H + 1, E.W + 1);
+                        }
                     }
                 }
             }

@@ -103,10 +103,13 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rec(const ConvRParams P) {
 
     // input DMA map: wave-instruction di = wave + 8 i covers LDS records [64 di, 64 di + 64) of a stage; hl = di / HALF_DMA
     auto make_ioff = [&](const WorkItem& it, unsigned (&ioff)[IS::PW]) {   // byte offsets inside the (K-step, hl) pair of planes
+        int ln = lane;
+        asm volatile("" : "+v"(ln));      // the (g, r, c) of a piece are re-derived per item (~10 VALU each): kept across the persistent loop they are
+                                          // 15 registers that the epilogue's peak (accumulators + two residual buffers) pushes into scratch
 #pragma unroll
         for (int i = 0; i < IS::PW; ++i) {
             const int di = wave + 8 * i;
-            int s = (di % IS::HALF_DMA) * 64 + lane;
+            int s = (di % IS::HALF_DMA) * 64 + ln;
             if (s >= IS::HALF) s = IS::HALF - 1;            // pad lanes shadow the last record (they land in the pad area)
             const int g = s / (ROWS * COLS), p = s - g * (ROWS * COLS);
             const int r = p / COLS, c = p - r * COLS;
@@ -276,14 +279,15 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rec(const ConvRParams P) {
         E.has_bias = P.bias != nullptr; E.has_act = P.yrec != nullptr && P.coef != nullptr;
         E.Cout = P.Cout; E.H = P.H; E.W = P.W; E.b = cur.b; E.kg = kg;
         E.HW = (size_t)P.H * P.W; E.planeO = plane; E.WpO = Wp;
-        const int x = cur.x0 + l31;
+        E.dbg = P.dbg;
+        int le = lane;
+        asm volatile("" : "+v"(le));      // (re-derived: a separate l31 kept alive through the epilogue goes to scratch)
+        const int x = cur.x0 + (le & 31);
         int ys[NROW];
 #pragma unroll
         for (int n = 0; n < NROW; ++n) ys[n] = cur.y0 + wr * NROW + n;
         if (!(P.dbg & 1)) {
-#pragma unroll
-            for (int m = 0; m < MW; ++m)
-                epilogue_mtile<1, NROW>(E, ec_l + par * EC_REC, acc[m], wm * MW + m, cur.cb * MT + wm * MW + m, ys, x, x < P.W);
+            epilogue_item<1, NROW, MW>(E, ec_l + par * EC_REC, acc, wm * MW, cur.cb * MT + wm * MW, ys, x, x < P.W);
         }
         stamp(2);
         ++item_no;
@@ -498,7 +502,7 @@ __global__ __launch_bounds__(512, 2) void k_upconv_rec(const ConvRParams P) {
         E.res = P.res; E.y32 = P.y32; E.yrec = P.yrec;
         E.has_bias = P.bias != nullptr; E.has_act = P.yrec != nullptr && P.coef != nullptr;
         E.Cout = P.Cout; E.H = P.H; E.W = P.W; E.b = cur.b; E.kg = kg;
-        E.HW = (size_t)P.H * P.W; E.planeO = (size_t)(P.H + 2) * rec_pitch(P.W); E.WpO = rec_pitch(P.W);
+        E.HW = (size_t)P.H * P.W; E.planeO = (size_t)(P.H + 2) * rec_pitch(P.W); E.WpO = rec_pitch(P.W); E.dbg = P.dbg;
         const int xi = cur.x0 + l31;
         int ys[NROW];
 #pragma unroll
@@ -507,9 +511,7 @@ __global__ __launch_bounds__(512, 2) void k_upconv_rec(const ConvRParams P) {
             ys[n] = yi < P.Hin ? 2 * yi + cur.a : P.H;      // rows past the input's last row: marked invalid
         }
         if (!(P.dbg & 1)) {
-#pragma unroll
-            for (int m = 0; m < MW; ++m)
-                epilogue_mtile<2, NROW>(E, ec_l + par * EC_REC, acc[m], wm * MW + m, cur.cb * MT + wm * MW + m, ys, 2 * xi, xi < P.Win);
+            epilogue_item<2, NROW, MW>(E, ec_l + par * EC_REC, acc, wm * MW, cur.cb * MT + wm * MW, ys, 2 * xi, xi < P.Win);
         }
         if (work_n >= total) break;
         work = work_n;
@@ -576,7 +578,7 @@ namespace mdt {
 size_t conv_bf16x3_direct_records(int cout, int cin);   // vae_conv_bf16x3.hip
 
 // MDTILE_REC_PERSIST=0: one item per block (A/B of the persistent schedule; read per launch so a probe can flip it in-process)
-constexpr int REC_STAGGER_PCT_DEFAULT = 0;      // (set from the A/B: profiles/r4u)
+constexpr int REC_STAGGER_PCT_DEFAULT = 0;      // off: -2 ... -5 % on single conv1 launches (profiles/r4u, r4v), nothing on the 8K decode (profiles/r4y: 1869 / 1870 vs 1870 / 1874 ms)
 
 static bool rec_persistent() {
     const char* e = getenv("MDTILE_REC_PERSIST");
@@ -673,9 +675,11 @@ int conv_rec_launch(const void* d_xrec, const void* d_w_rec, const float* d_bias
         if (rec_two_blocks(items16, items8, cus, up)) return conv_rec2_launch(P, B, up, s, num_cus());
     }
     // start-up stagger (stagger_start): spread = MDTILE_REC_STAGGER_PCT percent of an estimated item period, launches of >= 6 rounds only
+    // default: a quarter period for launches that write records ONLY (a conv1: -2 ... -5 % per launch, profiles/r4u, r4v; launches with an fp32
+    // stream run at their CU's own memory-pipe floor either way and only pay the late end)
     auto stagger = [&](long long items, int cus, unsigned period_ticks) {
         const char* e = getenv("MDTILE_REC_STAGGER_PCT");      // (read per launch: probes/conv_stagger_ab.py switches it between launches)
-        const int p = e ? atoi(e) : REC_STAGGER_PCT_DEFAULT;
+        const int p = e ? atoi(e) : ((!d_y32 && !d_res) ? REC_STAGGER_PCT_DEFAULT : 0);
         P.skew_ticks = (rec_persistent() && items >= 6LL * cus && p > 0) ? period_ticks * (unsigned)p / 100u : 0u;
     };
     if (up) {

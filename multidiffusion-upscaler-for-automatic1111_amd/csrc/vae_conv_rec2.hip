@@ -118,10 +118,12 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_rec2(const ConvRParams P) {
 
     // input DMA map: piece di = wave + 4 i covers LDS records [64 di, 64 di + 64) of a stage; hl = di / HALF_DMA
     auto make_ioff = [&](const Item2& it, unsigned (&ioff)[IS::PW]) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));      // (g, r, c) re-derived per item, as in k_conv3x3_rec: kept across the loop they go to scratch
 #pragma unroll
         for (int i = 0; i < IS::PW; ++i) {
             const int di = wave + NWV * i;
-            int s = (di % IS::HALF_DMA) * 64 + lane;
+            int s = (di % IS::HALF_DMA) * 64 + ln;
             if (s >= IS::HALF) s = IS::HALF - 1;            // pad lanes shadow the last record (they land in the pad area)
             const int g = s / (ROWS * COLS), p = s - g * (ROWS * COLS);
             const int r = p / COLS, c = p - r * COLS;
@@ -294,15 +296,15 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_rec2(const ConvRParams P) {
         E.res = P.res; E.y32 = P.y32; E.yrec = P.yrec;
         E.has_bias = P.bias != nullptr; E.has_act = P.yrec != nullptr && P.coef != nullptr;
         E.Cout = P.Cout; E.H = P.H; E.W = P.W; E.b = cur.b; E.kg = kg;
-        E.HW = (size_t)P.H * P.W; E.planeO = plane; E.WpO = Wp;
-        const int x = cur.x0 + l31;
+        E.HW = (size_t)P.H * P.W; E.planeO = plane; E.WpO = Wp; E.dbg = P.dbg;
+        int le = lane;
+        asm volatile("" : "+v"(le));      // (re-derived: a separate l31 kept alive through the epilogue goes to scratch)
+        const int x = cur.x0 + (le & 31);
         int ys[NROW];
 #pragma unroll
         for (int n = 0; n < NROW; ++n) ys[n] = cur.y0 + wr * NROW + n;
         if (!(P.dbg & 1)) {
-#pragma unroll
-            for (int m = 0; m < MW; ++m)
-                epilogue_mtile<1, NROW, 32>(E, ec_l + par * EC2, acc[m], wm * MW + m, cur.cb * MT + wm * MW + m, ys, x, x < P.W);
+            epilogue_item<1, NROW, MW, 32>(E, ec_l + par * EC2, acc, wm * MW, cur.cb * MT + wm * MW, ys, x, x < P.W);
         }
         if (!has_next) break;
         work = work_n;
@@ -540,7 +542,7 @@ __global__ __launch_bounds__(256, 2) void k_upconv_rec2(const ConvRParams P) {
         E.res = P.res; E.y32 = P.y32; E.yrec = P.yrec;
         E.has_bias = P.bias != nullptr; E.has_act = P.yrec != nullptr && P.coef != nullptr;
         E.Cout = P.Cout; E.H = P.H; E.W = P.W; E.b = cur.b; E.kg = kg;
-        E.HW = (size_t)P.H * P.W; E.planeO = (size_t)(P.H + 2) * rec_pitch(P.W); E.WpO = rec_pitch(P.W);
+        E.HW = (size_t)P.H * P.W; E.planeO = (size_t)(P.H + 2) * rec_pitch(P.W); E.WpO = rec_pitch(P.W); E.dbg = P.dbg;
         const int xi = cur.x0 + l31;
         int ys[NROW];
 #pragma unroll
@@ -549,9 +551,7 @@ __global__ __launch_bounds__(256, 2) void k_upconv_rec2(const ConvRParams P) {
             ys[n] = yi < P.Hin ? 2 * yi + cur.a : P.H;      // rows past the input's last row: marked invalid
         }
         if (!(P.dbg & 1)) {
-#pragma unroll
-            for (int m = 0; m < MW; ++m)
-                epilogue_mtile<2, NROW, 32>(E, ec_l + par * EC2, acc[m], wm * MW + m, cur.cb * MT + wm * MW + m, ys, 2 * xi, xi < P.Win);
+            epilogue_item<2, NROW, MW, 32>(E, ec_l + par * EC2, acc, wm * MW, cur.cb * MT + wm * MW, ys, 2 * xi, xi < P.Win);
         }
         if (!has_next) break;
         work = work_n;

@@ -16,12 +16,18 @@ for cin, cout, H, W in ((128, 128, 2224, 2224), (512, 512, 556, 556)):
     xrec = E.rec_from_f32(x, ci)
     forms = {"rec->rec": lambda: pc.call_rec(xrec, want_f32=False, want_rec=True, rec_coef=co),
              "rec->both(+res)": lambda: pc.call_rec(xrec, residual=res, want_f32=True, want_rec=True, rec_coef=co),
-             "rec->f32": lambda: pc.call_rec(xrec, want_f32=True)}
+             "rec->f32": lambda: pc.call_rec(xrec, want_f32=True),
+             "rec->f32+rec": lambda: pc.call_rec(xrec, want_f32=True, want_rec=True, rec_coef=co),
+             "rec->f32(+res)": lambda: pc.call_rec(xrec, residual=res, want_f32=True)}
+    if "--forms" in sys.argv:
+        forms = {k: v for k, v in forms.items() if k in sys.argv[sys.argv.index("--forms") + 1].split(",")}
+    XDBG = int(sys.argv[sys.argv.index("--dbg") + 1]) if "--dbg" in sys.argv else 0      # extra MDTILE_REC_DBG bits (16: no fp32 stores, 32: no record stores)
+    NARROW = False
     for name, fn in forms.items():
         for _ in range(3):
             fn()
         buf = torch.zeros(64 * 8 * 8, dtype=torch.int64, device=dev)
-        os.environ["MDTILE_REC_DBG"] = "8"
+        os.environ["MDTILE_REC_DBG"] = str((10 if NARROW else 8) | XDBG)
         os.environ["MDTILE_REC_STAMPS"] = hex(buf.data_ptr())
         fn()
         torch.cuda.synchronize()
