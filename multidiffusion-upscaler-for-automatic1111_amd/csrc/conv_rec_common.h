@@ -154,6 +154,43 @@ __device__ __forceinline__ gchar* uniform_ptr(gchar* p) { return uniform_ptr((co
 // the plane of accumulator value q is (q & 3) + 8 (q >> 2): walking q = 0..15 the uniform base advances by 1, 1, 1, 5, 1, 1, 1, 5, ... planes
 #define MDT_PLANE_STEP(q) (((q) & 3) ? 1 : 5)
 
+// ---- the residual of a conv2 arrives IN THE ACCUMULATORS (one-pixel-per-lane kernels).  The accumulator registers of an item are free from the
+// moment their rows are stored; the residual rows of the block's NEXT item are loaded into them right there, and that item's K loop starts
+// from them instead of from zero: y = ((res + sum of products) + bias).  The loads queue behind the stores in the CU's in-order memory pipe,
+// but nobody waits for them before the item-top vmcnt(0) that waits for the stores anyway -- in the form that read the residual inside the
+// epilogue every two-row unit stalled on a round trip stuck behind the previous unit's stores (36.5 k cycles against 21.1 k for the same
+// item without a residual, profiles/r4x).  No buffer registers at all.  The first item of a block loads its rows before the loop.
+template <int NROW>
+struct ResRows {
+    bool on;             // (wave-uniform) there is such an item
+    int b, mt_global0;   // image, first 32-cout tile of the wave
+    int ys[NROW];        // pixel rows of the wave
+    int x;               // the lane's pixel column
+    bool x_ok;
+};
+
+// rows n0 .. n0 + NR - 1 of tile m (clamped coordinates: unconditional loads, as in the epilogue form)
+template <int NROW, int MW, int NR>
+__device__ __forceinline__ void residual_into_acc(const float* res, int Cout, size_t HW, int H, int W, int kg, const ResRows<NROW>& R, int m, int n0,
+                                                  f32x16 (&acc)[MW][NROW][1]) {
+    const size_t HW4 = HW * sizeof(float);
+    unsigned kgo = (unsigned)kg;
+    asm volatile("" : "+v"(kgo));
+    const unsigned lane32 = ((4u * kgo) * (unsigned)HW + (unsigned)(R.x_ok ? R.x : 0)) * 4u;
+    const char* rb = reinterpret_cast<const char*>(res) + ((size_t)R.b * Cout + (size_t)(R.mt_global0 + m) * 32) * HW4;
+#pragma unroll
+    for (int n = 0; n < NR; ++n) {
+        const int yc = R.ys[n0 + n] < H ? R.ys[n0 + n] : H - 1;
+        const unsigned ro = lane32 + (unsigned)(yc * W) * 4u;
+        gchar* up = uniform_ptr(rb);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            if (q) up = uniform_ptr(up + MDT_PLANE_STEP(q) * HW4);
+            acc[m][n0 + n][0][q] = *(const MDT_GLOBAL float*)(up + (size_t)ro);
+        }
+    }
+}
+
 // NPX = 1: one pixel per lane; NPX = 2: the lane owns output px (2X, 2X+1) (sub-pixel upsample kernel)
 // ECS: float4 stride between the [bias | a | s] slots of the constants buffer (64 = 1 KB slots; 32 = packed 512 B slots)
 //
@@ -166,7 +203,8 @@ __device__ __forceinline__ gchar* uniform_ptr(gchar* p) { return uniform_ptr((co
 // 32-bit lane offsets: 20 HW < 2^32 (fp32) and 32 planeO < 2^32 (records), checked on the host (rec_image_ok).
 template <int NPX, int NROW, int MW, int ECS = 64>
 __device__ __forceinline__ void epilogue_item(const EpiCtx& E, const u32x4* ec, f32x16 (&acc)[MW][NROW][NPX], int mt_local0, int mt_global0,
-                                              const int (&ys)[NROW], int x, bool x_ok) {
+                                              const int (&ys)[NROW], int x, bool x_ok, const ResRows<NROW>& next) {
+    constexpr bool ACC_RES = NPX == 1;     // the residual is already in the accumulators (see ResRows); the sub-pixel kernel keeps the plain form
     // The wave's MW 32-cout tiles are walked in UNITS of RB pixel rows (one residual round trip each: 32 values per lane).  The residual of
     // unit u + 1 is requested before unit u is added, stored and activated, so that its HBM round trip (3-6 k cycles; four of them used to
     // be exposed per conv2 item) runs under that work.  One extra 32-register buffer: possible since the accesses are SGPR-based (a
@@ -182,7 +220,7 @@ __device__ __forceinline__ void epilogue_item(const EpiCtx& E, const u32x4* ec, 
     const size_t lo_half = (size_t)Pn * pl16;
     const unsigned rlane = (kgo * (unsigned)E.planeO + (unsigned)(xc + mdt::REC_COL0)) * 16u;      // padded column 0 of ... + x
 
-    constexpr bool AHEAD = NPX == 1;      // (the sub-pixel kernel holds two pixels per lane and is never given a residual by the decoder: plain form there)
+    constexpr bool AHEAD = false;         // (only the sub-pixel kernel reads a residual here -- the decoder never gives it one: plain form)
     float rbuf[AHEAD ? 2 : 1][RB][NPX][16];
     auto request_residual = [&](int u, float (&r)[RB][NPX][16]) {
         const int m = u / UPM, n0 = (u % UPM) * RB;
@@ -206,7 +244,7 @@ __device__ __forceinline__ void epilogue_item(const EpiCtx& E, const u32x4* ec, 
             }
         }
     };
-    if (AHEAD && E.res) request_residual(0, rbuf[0]);
+    if (!ACC_RES && AHEAD && E.res) request_residual(0, rbuf[0]);
 
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
@@ -232,7 +270,7 @@ __device__ __forceinline__ void epilogue_item(const EpiCtx& E, const u32x4* ec, 
                         acc[m][n][e][2 * j + 1] += bq[j].y;
                     }
         }
-        if (E.res) {
+        if (!ACC_RES && E.res) {
             if (!AHEAD) request_residual(u, rbuf[0]);
             else if (u + 1 < NU) request_residual(u + 1, rbuf[(u + 1) & 1]);
 #pragma unroll
@@ -332,6 +370,10 @@ __device__ __forceinline__ void epilogue_item(const EpiCtx& E, const u32x4* ec, 
                     }
                 }
             }
+        }
+        // the unit's accumulator rows are stored: the same rows of the block's next item (its residual) go into them now
+        if constexpr (NPX == 1) {
+            if (E.res && next.on) residual_into_acc<NROW, MW, RB>(E.res, E.Cout, E.HW, E.H, E.W, E.kg, next, m, n0, acc);
         }
     }
 }

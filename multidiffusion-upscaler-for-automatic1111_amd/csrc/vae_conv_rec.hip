@@ -190,8 +190,28 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rec(const ConvRParams P) {
     auto stamp = [&](int k) {
         if (stamps && lane == 0 && item_no < 64) stamps[(item_no * 8 + wave) * 8 + k] = __builtin_readcyclecounter();
     };
+    // a conv2's residual arrives in the accumulators (conv_rec_common.h: ResRows): the first item's rows are requested here, every later
+    // item's by the epilogue of the item before it
+    f32x16 acc[MW][NROW][1];
+    const bool res_in_acc = P.res != nullptr && !(P.dbg & 1);
+    auto res_rows = [&](const WorkItem& it, bool on) {
+        ResRows<NROW> R;
+        R.on = on; R.b = it.b; R.mt_global0 = it.cb * MT + wm * MW;
+#pragma unroll
+        for (int n = 0; n < NROW; ++n) R.ys[n] = it.y0 + wr * NROW + n;
+        int le = lane;
+        asm volatile("" : "+v"(le));
+        R.x = it.x0 + (le & 31);
+        R.x_ok = R.x < P.W;
+        return R;
+    };
+    if (res_in_acc) {
+        const ResRows<NROW> R0 = res_rows(cur, true);
+#pragma unroll
+        for (int m = 0; m < MW; ++m) residual_into_acc<NROW, MW, NROW>(P.res, P.Cout, (size_t)P.H * P.W, P.H, P.W, kg, R0, m, 0, acc);
+    }
     while (true) {
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces of the item's first operands have landed
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces of the item's first operands have landed (and the residual rows)
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -203,13 +223,14 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rec(const ConvRParams P) {
         unsigned ioff_n[IS::PW];
         if (work_n < total) make_ioff(nxt, ioff_n);      // (outside the unrolled K loop: keeps its body under the unroll budget)
 
-        f32x16 acc[MW][NROW][1];
+        if (!res_in_acc) {
 #pragma unroll
-        for (int m = 0; m < MW; ++m)
+            for (int m = 0; m < MW; ++m)
 #pragma unroll
-            for (int n = 0; n < NROW; ++n)
+                for (int n = 0; n < NROW; ++n)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) acc[m][n][0][q] = 0.0f;
+                    for (int q = 0; q < 16; ++q) acc[m][n][0][q] = 0.0f;
+        }
 
         // one trip = 2 K-steps = 6 phases = 18 steps = 36 half-steps: ring slot (= dy), input stage (= kk) and both register-set
         // parities are compile-time constants inside the unrolled body
@@ -287,7 +308,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rec(const ConvRParams P) {
 #pragma unroll
         for (int n = 0; n < NROW; ++n) ys[n] = cur.y0 + wr * NROW + n;
         if (!(P.dbg & 1)) {
-            epilogue_item<1, NROW, MW>(E, ec_l + par * EC_REC, acc, wm * MW, cur.cb * MT + wm * MW, ys, x, x < P.W);
+            epilogue_item<1, NROW, MW>(E, ec_l + par * EC_REC, acc, wm * MW, cur.cb * MT + wm * MW, ys, x, x < P.W, res_rows(nxt, work_n < total));
         }
         stamp(2);
         ++item_no;
@@ -511,7 +532,7 @@ __global__ __launch_bounds__(512, 2) void k_upconv_rec(const ConvRParams P) {
             ys[n] = yi < P.Hin ? 2 * yi + cur.a : P.H;      // rows past the input's last row: marked invalid
         }
         if (!(P.dbg & 1)) {
-            epilogue_item<2, NROW, MW>(E, ec_l + par * EC_REC, acc, wm * MW, cur.cb * MT + wm * MW, ys, 2 * xi, xi < P.Win);
+            epilogue_item<2, NROW, MW>(E, ec_l + par * EC_REC, acc, wm * MW, cur.cb * MT + wm * MW, ys, 2 * xi, xi < P.Win, ResRows<NROW>{});
         }
         if (work_n >= total) break;
         work = work_n;

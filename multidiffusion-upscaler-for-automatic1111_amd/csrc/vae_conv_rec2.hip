@@ -194,6 +194,25 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_rec2(const ConvRParams P) {
     startup_skew(P, wave, lane);
     int par = 0, r0 = 0;
 
+    // a conv2's residual arrives in the accumulators, as in k_conv3x3_rec (conv_rec_common.h: ResRows)
+    f32x16 acc[MW][NROW][1];
+    const bool res_in_acc = P.res != nullptr && !(P.dbg & 1);
+    auto res_rows = [&](const Item2& it, bool on) {
+        ResRows<NROW> R;
+        R.on = on; R.b = it.b; R.mt_global0 = it.cb * MT + wm * MW;
+#pragma unroll
+        for (int n = 0; n < NROW; ++n) R.ys[n] = it.y0 + wr * NROW + n;
+        int le = lane;
+        asm volatile("" : "+v"(le));
+        R.x = it.x0 + (le & 31);
+        R.x_ok = R.x < P.W;
+        return R;
+    };
+    if (res_in_acc) {
+        const ResRows<NROW> R0 = res_rows(cur, true);
+#pragma unroll
+        for (int m = 0; m < MW; ++m) residual_into_acc<NROW, MW, NROW>(P.res, P.Cout, (size_t)P.H * P.W, P.H, P.W, kg, R0, m, 0, acc);
+    }
     while (true) {
         MDT_WAITV(0);          // this wave's pieces of the item's first operands have landed (and its stores of the last item are out)
         MDT_BARRIER();
@@ -204,13 +223,14 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_rec2(const ConvRParams P) {
         unsigned ioff_n[IS::PW];
         if (has_next) make_ioff(nxt, ioff_n);
 
-        f32x16 acc[MW][NROW][1];
+        if (!res_in_acc) {
 #pragma unroll
-        for (int m = 0; m < MW; ++m)
+            for (int m = 0; m < MW; ++m)
 #pragma unroll
-            for (int n = 0; n < NROW; ++n)
+                for (int n = 0; n < NROW; ++n)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) acc[m][n][0][q] = 0.0f;
+                    for (int q = 0; q < 16; ++q) acc[m][n][0][q] = 0.0f;
+        }
 
         // one trip = 2 K-steps = 18 steps: register sets (fw: step parity, fx: half-step) and the input stage are compile-time,
         // the ring slot is rb + u (mod 4) with the trip's origin rb in a scalar register
@@ -304,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_rec2(const ConvRParams P) {
 #pragma unroll
         for (int n = 0; n < NROW; ++n) ys[n] = cur.y0 + wr * NROW + n;
         if (!(P.dbg & 1)) {
-            epilogue_item<1, NROW, MW, 32>(E, ec_l + par * EC2, acc, wm * MW, cur.cb * MT + wm * MW, ys, x, x < P.W);
+            epilogue_item<1, NROW, MW, 32>(E, ec_l + par * EC2, acc, wm * MW, cur.cb * MT + wm * MW, ys, x, x < P.W, res_rows(nxt, has_next));
         }
         if (!has_next) break;
         work = work_n;
@@ -551,7 +571,7 @@ __global__ __launch_bounds__(256, 2) void k_upconv_rec2(const ConvRParams P) {
             ys[n] = yi < P.Hin ? 2 * yi + cur.a : P.H;      // rows past the input's last row: marked invalid
         }
         if (!(P.dbg & 1)) {
-            epilogue_item<2, NROW, MW, 32>(E, ec_l + par * EC2, acc, wm * MW, cur.cb * MT + wm * MW, ys, 2 * xi, xi < P.Win);
+            epilogue_item<2, NROW, MW, 32>(E, ec_l + par * EC2, acc, wm * MW, cur.cb * MT + wm * MW, ys, 2 * xi, xi < P.Win, ResRows<NROW>{});
         }
         if (!has_next) break;
         work = work_n;
