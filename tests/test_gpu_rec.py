@@ -342,6 +342,36 @@ def test_two_blocks_per_cu_kernels_are_bit_identical_to_the_one_block_kernels(pl
         assert torch.equal(r1.records(), r2.records()), f"record output differs (skew mode {skew})"
 
 
+@pytest.mark.parametrize("cin,cout,H,W,up,res", [(128, 128, 1200, 1056, False, True), (128, 128, 1200, 1056, False, False), (64, 128, 1088, 1056, True, False)])
+def test_many_items_per_block_and_the_start_up_stagger(plugin, cuda, monkeypatch, cin, cout, H, W, up, res):
+    """Launches of more than six item rounds per CU (the persistent loop runs long: ring slots, input stages and -- for a conv2 -- the
+    residual rows that the epilogue of item i loads into the accumulators of item i + 1 all run on across item boundaries), against torch
+    fp32; and the same launch with the start-up stagger of the persistent blocks on (MDTILE_REC_STAGGER_PCT, csrc/vae_conv_rec.hip:
+    stagger_start -- a delay only): bit for bit the same output."""
+    E = plugin.engine
+    torch.manual_seed(cin + cout + H)
+    conv = torch.nn.Conv2d(cin, cout, 3, 1, 1)
+    hin, win = (H // 2, W // 2) if up else (H, W)
+    x = torch.randn(1, cin, hin, win)
+    out_coef = _coef(1, cout, 11).to(cuda)
+    pc = E.PackedConv(conv.weight.detach().to(cuda), conv.bias.detach().to(cuda))
+    xrec = E.rec_from_f32(x.to(cuda), None)
+    rr = torch.randn(1, cout, H, W).to(cuda) if res else None
+    monkeypatch.setenv("MDTILE_REC_BLOCKS", "1")
+    monkeypatch.setenv("MDTILE_REC_STAGGER_PCT", "0")
+    y0, r0 = pc.call_rec(xrec, residual=rr, upsample2x=up, want_f32=True, want_rec=True, rec_coef=out_coef)
+    xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if up else x
+    ref = F.conv2d(xin.to(cuda), conv.weight.detach().to(cuda), conv.bias.detach().to(cuda), padding=1)
+    if res:
+        ref = ref + rr
+    assert _rel(y0, ref) <= 5e-5
+    assert _rel(r0.to_f32(), _act(ref, out_coef)) <= 5e-5
+    for pct in ("50", "100"):
+        monkeypatch.setenv("MDTILE_REC_STAGGER_PCT", pct)
+        y1, r1 = pc.call_rec(xrec, residual=rr, upsample2x=up, want_f32=True, want_rec=True, rec_coef=out_coef)
+        assert torch.equal(y0, y1) and torch.equal(r0.records(), r1.records()), f"stagger {pct} % changed the output"
+
+
 @pytest.mark.parametrize("blocks", ["1", "2"], ids=["one_block_per_cu", "two_blocks_per_cu"])
 def test_upconv_windows_under_both_kernel_families(plugin, cuda, monkeypatch, blocks):
     """mdtile_upconv2d_rec_window (per-image window origins inside a larger input image, live-window narrowing of the decoder tiles) through
