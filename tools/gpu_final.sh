@@ -5,11 +5,11 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out
-(timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tail -40) > $O/pytest_gpu_$TAG.log 2>&1
+(timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tail -40) > $O/pytest_gpu_$TAG.log 2>&1
 (timeout 300 python __graft_entry__.py smoke 2>&1 | tail -3) > $O/smoke_$TAG.log 2>&1
 (timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 1 --warmup 1 --no-cpu-baseline --debug-single-device 2>&1 | tail -15) > $O/bench_n2_debug_$TAG.log 2>&1
 cd /tmp
-(timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$TAG -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile-pass 2>&1 | tail -3) > $O/pmc_fetch_$TAG.log 2>&1
+(timeout 600 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_fetch_$TAG -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile-pass 2>&1 | tail -3) > $O/pmc_fetch_$TAG.log 2>&1
 (timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$TAG -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile-pass 2>&1 | tail -3) > $O/pmc_write_$TAG.log 2>&1
 cd $R
 (python tools/pmc_summary.py $O/pmc_fetch_$TAG $O/pmc_write_$TAG $O/pmc_hbm_summary_$TAG.json) > $O/pmc_summary_$TAG.log 2>&1
