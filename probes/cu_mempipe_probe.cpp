@@ -49,7 +49,9 @@ __global__ __launch_bounds__(1024) void k_pipe(const char* __restrict__ src, uns
     u32x4 acc = {0u, 0u, 0u, 0u};
     unsigned acc1 = 0;
     char* mine = dst + (size_t)blockIdx.x * (4 << 20);
-    unsigned pos = (blockIdx.x * 7919u + wave * 104729u) % (src_bytes >> 10);      // in KB units
+    // (a cold source -- larger than the 256 MB Infinity Cache -- is walked as a stream: block b, wave w start far apart and advance by nw KB)
+    unsigned pos = src_bytes > (64u << 20) ? (unsigned)(((unsigned long long)(blockIdx.x * nw + wave) * 2654435761ull) % (src_bytes >> 10))
+                                           : (blockIdx.x * 7919u + wave * 104729u) % (src_bytes >> 10);      // in KB units
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -147,5 +149,27 @@ int main() {
             printf("%-34s %6d %6d | %10.1f %10.1f %12.2f\n", names[kind], grid, threads / 64, gbs, gbs / 2.4, gbs * grid * 1e-3);
         }
     }
+    // ---- the same loads from a COLD source (2 GB streamed once: every line comes from HBM): what a CU pulls when nothing is resident -- the
+    // residual stream of a conv2 epilogue (DESIGN.md section 3 "Late round 4")
+    char* cold;
+    const unsigned cold_bytes = 2047u << 20;
+    CK(hipMalloc(&cold, cold_bytes));
+    CK(hipMemset(cold, 1, cold_bytes));
+    printf("cold source: %u MB (beyond the Infinity Cache), each line touched once per pass\n", cold_bytes >> 20);
+    for (int kind = 0; kind < 3; ++kind)
+        for (int cfg = 0; cfg < 2; ++cfg) {
+            const int grid = cfg == 1 ? 32 : cus, threads = 512;
+            // bytes per block and pass = 8 waves x iters x 8 x bytes_per: keep every pass inside the source without reuse
+            const int iters = kind == 2 ? 256 : 64;
+            double t = 0;
+            switch (kind) {
+                case 0: t = run<DMA, 8>(cold, cold_bytes, dst, sink, grid, threads, iters); break;
+                case 1: t = run<LOAD16, 8>(cold, cold_bytes, dst, sink, grid, threads, iters); break;
+                default: t = run<LOAD4, 8>(cold, cold_bytes, dst, sink, grid, threads, iters); break;
+            }
+            const double bytes_cu = (double)(threads / 64) * iters * 8 * bytes_per[kind];
+            const double gbs = bytes_cu / t * 1e-9;
+            printf("cold %-29s %6d %6d | %10.1f %10.1f %12.2f\n", names[kind], grid, threads / 64, gbs, gbs / 2.4, gbs * grid * 1e-3);
+        }
     return 0;
 }
