@@ -79,11 +79,9 @@ __device__ __forceinline__ float silu_f(float t) { return t * __builtin_amdgcn_r
 
 // ---- shared epilogue: one 32-cout tile of a wave (NROW pixel rows x NPX pixels per lane) -> + bias (+ residual) -> fp32 NCHW
 // and / or record image.  C/D layout of a 32x32 MFMA: col = lane & 31 (pixel), row = (q&3) + 8*(q>>2) + 4*(lane>>5) (cout).
-// The epilogue is latency-, not bandwidth-bound (one block per CU, nothing else to run meanwhile), so it is built to expose
-// as few memory round trips as possible:
-//   * the per-channel constants (bias, and the (a, s) of the record output's activation) of the item's 128 couts are DMA'd
-//     into a 3 x 1 KB LDS buffer together with the item's first operands -- the epilogue reads them with ds_read_b128;
-//   * the residual is requested 32 values per lane at a time (two pixel rows) before the first of them is used.
+// The per-channel constants (bias, and the (a, s) of the record output's activation) of the item's 128 couts are DMA'd into a
+// 3 x 1 KB LDS buffer together with the item's first operands -- the epilogue reads them with ds_read_b128 where it uses them.
+// A conv2's residual does not pass through here at all in the one-pixel-per-lane kernels: it is in the accumulators (ResRows below).
 struct EpiCtx {
     const float* __restrict__ res;
     float* __restrict__ y32;
@@ -194,21 +192,21 @@ __device__ __forceinline__ void residual_into_acc(const float* res, int Cout, si
 // NPX = 1: one pixel per lane; NPX = 2: the lane owns output px (2X, 2X+1) (sub-pixel upsample kernel)
 // ECS: float4 stride between the [bias | a | s] slots of the constants buffer (64 = 1 KB slots; 32 = packed 512 B slots)
 //
-// Round 4, late: the epilogue is bound by the wave's own VALU issue, not by the memory pipe -- hipcc's code for
-// the first form spent ~100 VALU instructions per 8-value record (per-value converts, 64-bit address arithmetic per access, an
-// activation computed and then selected away when there was none, a Cout test and five SGPR-spill reloads in front of every fp32
-// store).  This form addresses every access as (wave-uniform 64-bit base) + (32-bit lane offset) -- global_* with an SGPR base --
-// so an access costs scalar adds only; the uniform bases are formed per item from an `opaque` plane size, or LLVM hoists 16 of them
-// per tensor out of the persistent loop and spills them to VGPR lanes (two v_readlane per use).
+// Round 4, late (DESIGN.md section 3 "Late round 4"): hipcc's code for the first form of this epilogue spent ~100 VALU instructions per
+// 8-value record (per-value converts, 64-bit address arithmetic per access, an activation computed and then selected away when there
+// was none, a Cout test and five SGPR-spill reloads in front of every fp32 store) -- with two waves per SIMD that was as long as the
+// store drain it should have hidden behind.  This form addresses every access as (wave-uniform 64-bit base) + (32-bit lane offset) --
+// global_* with an SGPR base -- so an access costs scalar adds only; the uniform bases are formed per item behind an opaque asm, or
+// LLVM hoists 16 of them per tensor out of the persistent loop and spills them to VGPR lanes (two v_readlane per use).  What is left is
+// the CU's memory pipe: ~27 B/clk of stores, 256 KB (records) + 256 KB (fp32) per item.
 // 32-bit lane offsets: 20 HW < 2^32 (fp32) and 32 planeO < 2^32 (records), checked on the host (rec_image_ok).
 template <int NPX, int NROW, int MW, int ECS = 64>
 __device__ __forceinline__ void epilogue_item(const EpiCtx& E, const u32x4* ec, f32x16 (&acc)[MW][NROW][NPX], int mt_local0, int mt_global0,
                                               const int (&ys)[NROW], int x, bool x_ok, const ResRows<NROW>& next) {
     constexpr bool ACC_RES = NPX == 1;     // the residual is already in the accumulators (see ResRows); the sub-pixel kernel keeps the plain form
-    // The wave's MW 32-cout tiles are walked in UNITS of RB pixel rows (one residual round trip each: 32 values per lane).  The residual of
-    // unit u + 1 is requested before unit u is added, stored and activated, so that its HBM round trip (3-6 k cycles; four of them used to
-    // be exposed per conv2 item) runs under that work.  One extra 32-register buffer: possible since the accesses are SGPR-based (a
-    // 64-bit vector address per load had cost 64 more).
+    // The wave's MW 32-cout tiles are walked in UNITS of RB pixel rows: bias, (sub-pixel kernel: residual), fp32 stores, activation + split +
+    // record stores, and -- one-pixel-per-lane kernels with a residual -- the same rows of the block's next item loaded into the registers
+    // the unit has just stored from.
     constexpr int RB = NPX == 1 ? 2 : 1, UPM = NROW / RB, NU = MW * UPM;
     const size_t HW4 = E.HW * sizeof(float);
     const int xc = x_ok ? x : 0;                                  // clamped column for the unconditional residual loads
@@ -220,8 +218,7 @@ __device__ __forceinline__ void epilogue_item(const EpiCtx& E, const u32x4* ec, 
     const size_t lo_half = (size_t)Pn * pl16;
     const unsigned rlane = (kgo * (unsigned)E.planeO + (unsigned)(xc + mdt::REC_COL0)) * 16u;      // padded column 0 of ... + x
 
-    constexpr bool AHEAD = false;         // (only the sub-pixel kernel reads a residual here -- the decoder never gives it one: plain form)
-    float rbuf[AHEAD ? 2 : 1][RB][NPX][16];
+    float rbuf[RB][NPX][16];              // (the sub-pixel kernel's residual rows: read here, in the plain form -- the decoder never gives it one)
     auto request_residual = [&](int u, float (&r)[RB][NPX][16]) {
         const int m = u / UPM, n0 = (u % UPM) * RB;
         const char* rb = reinterpret_cast<const char*>(E.res) + ((size_t)E.b * E.Cout + (size_t)(mt_global0 + m) * 32) * HW4;
@@ -244,7 +241,6 @@ __device__ __forceinline__ void epilogue_item(const EpiCtx& E, const u32x4* ec, 
             }
         }
     };
-    if (!ACC_RES && AHEAD && E.res) request_residual(0, rbuf[0]);
 
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
@@ -271,14 +267,13 @@ __device__ __forceinline__ void epilogue_item(const EpiCtx& E, const u32x4* ec, 
                     }
         }
         if (!ACC_RES && E.res) {
-            if (!AHEAD) request_residual(u, rbuf[0]);
-            else if (u + 1 < NU) request_residual(u + 1, rbuf[(u + 1) & 1]);
+            request_residual(u, rbuf);
 #pragma unroll
             for (int n = 0; n < RB; ++n)
 #pragma unroll
                 for (int e = 0; e < NPX; ++e)
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) acc[m][n0 + n][e][q] += rbuf[AHEAD ? (u & 1) : 0][n][e][q];
+                    for (int q = 0; q < 16; ++q) acc[m][n0 + n][e][q] += rbuf[n][e][q];
         }
         // ---- fp32 tensor: plane of value q = uniform base + ((q&3) + 8 (q>>2)) HW; lane = 4 kg HW + y W + x
         // ---- record image: plane ((mt*2 + R)*2 + kg) of the hi half, the lo half Cout/8 planes further; lane = kg plane + row + column
