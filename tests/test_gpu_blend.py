@@ -109,6 +109,10 @@ CONFIGS = [  # BASELINE.json configs at full latent size
     ("cfg4_ov64", "mod", 1024, 1024, 128, 128, 64, 4), ("cfg4_ov64_md", "md", 1024, 1024, 128, 128, 64, 4),
     # 441 tile batches: more than the 320 pointers that ride in the kernel arguments -> the packed-buffer form behind the same calls
     ("b441_md", "md", 1024, 1024, 96, 96, 48, 1), ("b441_mod", "mod", 1024, 1024, 96, 96, 48, 1),
+    # rectangular canvases and tiles; regular grids (every origin = index x stride: 48 x 80, 56 x 56 -- cfg4 above is one too) and one that is
+    # regular along y only
+    ("reg_rect_md", "md", 640, 416, 64, 96, 16, 4), ("reg_rect_mod", "mod", 640, 416, 64, 96, 16, 4), ("reg_sq_md", "md", 512, 512, 64, 64, 8, 4),
+    ("reg_y_only_mod", "mod", 512, 416, 96, 96, 16, 4),
 ]
 
 
