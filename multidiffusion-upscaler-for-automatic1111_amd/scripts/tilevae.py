@@ -37,7 +37,8 @@ import os as _os
 FUSE_PRE_GN = _os.environ.get("MDTILE_FUSE_GN", "1") != "0"
 # fast mode with every norm frozen: activations travel between the 3x3 convs as split-bf16 record images that the PRODUCING
 # conv writes already normalised + SiLU'd (engine: mdtile_conv2d_rec); MDTILE_REC=0 keeps the fp32 hand-over (A/B, debugging)
-TILE_BATCH = int(_os.environ.get("MDTILE_TILE_BATCH", "3"))     # fast mode: tiles of equal shape per sweep (see vae_tile_forward)
+TILE_BATCH = int(_os.environ.get("MDTILE_TILE_BATCH", "4"))     # fast mode: tiles of equal shape per sweep (see vae_tile_forward); 4 = the four
+# corners / top-bottom edges / left-right edges / interior tiles of a 4 x 4 grid each go as ONE stack (3 left a single-tile sweep per group: profiles/r5d)
 REC_PATH = _os.environ.get("MDTILE_REC", "1") != "0"
 # fast-mode decoder tiles shed their dead border where the resolution doubles (live_windows below); 0 = decode the whole padded tile
 LIVE_WINDOW = _os.environ.get("MDTILE_LIVE_WINDOW", "1") != "0"
@@ -667,7 +668,7 @@ class VAEHook:
                 # walks them one by one (:578-642); with frozen statistics they are independent, so the result is the same -- but
                 # a conv launch over one tile fills the 256 CUs in ceil(items / 256) rounds and the last round is mostly empty
                 # (256 -> 256 at 1112^2: 4 900 items = 19.1 rounds, 4 % idle; 512 -> 512 at 278^2: 2.5 rounds, 16 % idle).
-                # 288 GB of HBM hold several tiles' activations at once (3 tiles of 278^2: ~40 GB).
+                # 288 GB of HBM hold several tiles' activations at once (4 tiles of 278^2: ~53 GB).
                 # Tiles stack by (shape, window SIZES of their narrowed upsample convs): each tile keeps its own window ORIGIN
                 # (mdtile_upconv2d_rec_window takes one per image), so e.g. the interior tiles of every row share their launches.  A chunk
                 # runs start to finish in ONE pass -- round 3 cut the sweep in front of the first narrowed conv to stack the 1x level by
