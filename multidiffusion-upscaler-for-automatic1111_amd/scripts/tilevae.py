@@ -40,6 +40,8 @@ FUSE_PRE_GN = _os.environ.get("MDTILE_FUSE_GN", "1") != "0"
 TILE_BATCH = int(_os.environ.get("MDTILE_TILE_BATCH", "4"))     # fast mode: tiles of equal shape per sweep (see vae_tile_forward); 4 = the four
 # corners / top-bottom edges / left-right edges / interior tiles of a 4 x 4 grid each go as ONE stack (3 left a single-tile sweep per group: profiles/r5d)
 REC_PATH = _os.environ.get("MDTILE_REC", "1") != "0"
+# slow mode and the estimator pass: the record kernels at the pooled-statistics sites where they pay (VAEHook._pooled_site_takes_rec); 0 = fp32 hand-over
+SLOW_REC = _os.environ.get("MDTILE_SLOW_REC", "1") != "0"
 # fast-mode decoder tiles shed their dead border where the resolution doubles (live_windows below); 0 = decode the whole padded tile
 LIVE_WINDOW = _os.environ.get("MDTILE_LIVE_WINDOW", "1") != "0"
 # multi-GPU fast mode: run the GroupNorm estimator sequence-parallel across the ranks (mdtile/seqpar.py); 0 = every rank
@@ -326,6 +328,11 @@ class VAEHook:
             elif s.kind == "conv":
                 if s.downsample:
                     st.x = s.conv.down2(st.x)
+                elif self._pooled_site_takes_rec(s):
+                    # pooled-statistics site on the record kernels: one conversion pass (norm + SiLU fused into it) + the record conv --
+                    # bit for bit the fp32 hand-over kernel's output, cheaper where _pooled_site_takes_rec says so
+                    xrec = self.engine.rec_from_f32(st.x, st.pre)
+                    st.x, _ = s.conv.call_rec(xrec, residual=st.res.pop() if s.fuse_res else None, upsample2x=s.upsample, want_f32=True, want_rec=False)
                 else:
                     st.x = s.conv(st.x, residual=st.res.pop() if s.fuse_res else None, upsample2x=s.upsample, pre_gn=st.pre)
                 st.pre = None
@@ -334,6 +341,16 @@ class VAEHook:
             elif s.kind == "tanh":
                 st.x = self.engine.tanh(st.x)
             st.pc += 1
+
+    def _pooled_site_takes_rec(self, s: Step) -> bool:
+        """Slow mode / the estimator pass: a norm whose statistics are pooled cannot be applied by the conv that PRODUCES its input, so the
+        record kernels cost an extra conversion pass (fp32 -> activated records) there.  They still win where the conv is long against its
+        activation: the 512 -> 512 layers (-7 ... -9 % incl. the pass) and every upsample conv (the pass runs on the quarter-size input:
+        -8 ... -21 %); at 256 / 128 input channels the pass costs more than the faster conv saves (+1 ... +8 %) -- profiles/r4z/conv_probe.log."""
+        if not (SLOW_REC and REC_PATH and hasattr(self.engine, "rec_from_f32") and self._takes_rec(s)):
+            return False
+        c = s.conv
+        return bool(s.upsample or (getattr(c, "cin", 0) >= 512 and getattr(c, "cout", 0) >= 512))
 
     def _tile_batch_that_fits(self, N: int, tile_hw: Tuple[int, int], dev) -> int:
         """Tiles of one shape per sweep (TILE_BATCH at most): what 60 % of the free device memory holds.  Peak of one tile: about five
