@@ -147,6 +147,40 @@ def _rec_hook(net, ts, fast=True, rec_convs=True):
     return hook
 
 
+@pytest.mark.parametrize("fast", [False, True], ids=["slow_mode", "estimator_pass"])
+def test_pooled_statistics_sites_take_the_record_kernels_where_they_pay(monkeypatch, fast):
+    """A norm whose statistics are pooled (slow mode; every norm of the fast mode's estimator pass) cannot be applied by the conv that
+    produces its input: there the record kernels run behind a conversion pass (rec_from_f32 with the norm's (a, s) + SiLU), and only at the
+    sites VAEHook._pooled_site_takes_rec names -- every upsample conv and the 512 -> 512 layers.  Same result as the fp32 hand-over form
+    (MDTILE_SLOW_REC=0) and as the oracle."""
+    from hostsim import ldm_decoder as ld
+    from oracle import vae_oracle as vo
+    import torch_engine as te
+    torch.manual_seed(5)
+    z = torch.randn(1, 4, 36, 44)
+    outs, used = {}, {}
+    for on in (True, False):
+        hook = _rec_hook(ld.make_decoder(0, small=True), 16, fast=fast)
+        pl = sys.modules[type(hook).__module__]
+        monkeypatch.setattr(pl, "SLOW_REC", on)
+        if fast:
+            monkeypatch.setattr(pl, "REC_PATH", on)       # (the tile sweep itself off the record doubles: only the estimator's calls are counted)
+        te.TorchConvRec.px_computed = 0
+        with torch.no_grad():
+            outs[on] = hook(z)
+        used[on] = te.TorchConvRec.px_computed
+        # the rule itself, on stand-in steps: upsample convs always, plain convs only at 512 -> 512
+        monkeypatch.setattr(pl, "REC_PATH", True)
+        mk = lambda cin, cout, up: pl.Step("conv", conv=type("C", (), {"cin": cin, "cout": cout, "takes_rec": lambda self, u=False: True})(), upsample=up)
+        assert hook._pooled_site_takes_rec(mk(256, 256, True)) == on and hook._pooled_site_takes_rec(mk(512, 512, False)) == on
+        assert not hook._pooled_site_takes_rec(mk(256, 256, False)) and not hook._pooled_site_takes_rec(mk(512, 256, False))
+    assert used[True] > 0 and used[False] == 0              # the small decoder has no 512-channel layer: its three upsample convs per pass
+    assert torch.allclose(outs[True], outs[False], rtol=0, atol=1e-5 * outs[False].abs().max().item())
+    with torch.no_grad():
+        ref = vo.tiled_forward(ld.make_decoder(0, small=True), z, 16, fast)
+    assert (outs[True] - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
 def test_live_windows_of_the_sd_decoder_program():
     """Grow = 1 / 3 / 6 latent px behind the 8x / 4x / 2x upsample convs (3 resblocks per level + conv_out), the 1x level whole; windows
     nest, are clamped to the tile and are given in input px of each upsample conv relative to its already narrowed input plane."""
