@@ -70,6 +70,7 @@ def parse():
     ap.add_argument("--no-f32-pass", action="store_true", help="skip the strict-fp32 companion decode (parity.rel_err_vs_f32, value_f32)")
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the per-stage split and the HIP-event roofline pass (PMC runs)")
     ap.add_argument("--no-oracle-pass", action="store_true", help="skip parity.rel_err_vs_oracle (assembled cfg3 decode vs the oracle on the GPU, untimed)")
+    ap.add_argument("--no-stress-pass", action="store_true", help="skip parity.rel_err_vs_oracle_stress (cfg3 decode of the trained-like 'stress' decoder vs the oracle on the GPU, untimed)")
     ap.add_argument("--cpu-vae-latent", type=int, default=88, help="width of the 64-row latent of the CPU VAE sample")
     ap.add_argument("--debug-single-device", action="store_true",
                     help="functional check of the N > 1 flow on ONE GPU: every rank uses cuda:0 and gloo (host-staged) instead "
@@ -569,6 +570,45 @@ def main():
                                              f"tiles of the same latent with its own estimator statistics (torch fp32 on this GPU, {t_or8:.0f} s); "
                                              "errors relative to the image's absolute maximum"})
             del img8, crops
+
+    # ------------------------------------------------------------------ parity on TRAINED-LIKE statistics (untimed)
+    # Every number above is taken on default-init weights (activations ~ N(0,1), near-uniform softmax rows, no cancellation).  The
+    # split-bf16 default precision has 16 significand bits per factor; its error grows with sum|a.w| / |sum a.w|.  Same cfg3 decode
+    # with hostsim/ldm_decoder.py's committed "stress" recipe (conv gains 1..4, N(0,1) biases, zero-sum 3x3 filters on a third of the
+    # output channels, GroupNorm gamma 0.2..3 / beta -2..2, 2 % of the residual stream x100 at mid.block_1, attention logits at
+    # std 8): default precision AND the strict-fp32 engine against the oracle on this GPU.  tests/test_gpu_vae_stress.py holds the
+    # same as tests (plus logit std 16 / 32, slow mode, the CPU oracle at tile 64).
+    if rank == 0 and world == 1 and hook is not None and not args.no_stress_pass:
+        from oracle import gpu_reference as gr
+        dec_s = ld.make_decoder(0, stress=8).to(dev)
+        dec_s.original_forward = dec_s.forward
+        zs = torch.randn(1, 4, 512, 512, generator=torch.Generator(device="cpu").manual_seed(5))
+        builtins.print = lambda *a, **k: None
+        try:
+            t0 = time.perf_counter()
+            ref = gr.tiled_forward_gpu(dec_s, zs, args.vae_tile, fast=not args.slow_vae).cpu()
+            t_oracle_s = time.perf_counter() - t0
+            torch.cuda.empty_cache()
+            hook_s = pl.tilevae.VAEHook(dec_s, args.vae_tile, is_decoder=True, fast_decoder=not args.slow_vae, fast_encoder=False, color_fix=False)
+            out = hook_s(zs.to(dev)).float().cpu()
+            try:
+                E.set_precision(E.PRECISION_F32)
+                out32 = hook_s(zs.to(dev)).float().cpu()
+            finally:
+                E.set_precision(E.PRECISION_BF16X3)
+        finally:
+            builtins.print = _print
+        den = ref.abs().max().item()
+        parity = parity or {"tolerance": 1e-3}
+        parity.update({"rel_err_vs_oracle_stress": float((out - ref).abs().max().item() / den),
+                       "rms_err_vs_oracle_stress": float(((out - ref).pow(2).mean().sqrt() / den).item()),
+                       "rel_err_vs_oracle_stress_f32_engine": float((out32 - ref).abs().max().item() / den),
+                       "stress_what": f"assembled decode of a 512x512 latent (BASELINE cfg3) at decoder tile {args.vae_tile}, {'slow' if args.slow_vae else 'fast'} mode, of the "
+                                      "trained-like 'stress' decoder (hostsim/ldm_decoder.py: apply_stress): default precision and the strict-fp32 engine vs the oracle on "
+                                      f"torch fp32 on this GPU ({t_oracle_s:.0f} s); output range {den:.2f}; bar 2e-4",
+                       "stress_recipe": getattr(dec_s, "stress_info", None)})
+        del ref, out, out32, hook_s, dec_s
+        torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ CPU baseline (oracle = port of the reference), rank 0, N=1
     cpu_baseline = None

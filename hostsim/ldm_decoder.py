@@ -15,6 +15,8 @@ the product and the oracle read; its own eager `forward` is what oracle/vae_orac
 """
 from __future__ import annotations
 
+import math
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -166,13 +168,87 @@ class Encoder(nn.Module):
         return self.conv_out(F.silu(self.norm_out(h)))
 
 
-def make_decoder(seed: int = 0, small: bool = False, **kw) -> Decoder:
+def _logit_std(attn: "AttnBlock", h: torch.Tensor) -> float:
+    """Standard deviation of the scaled attention logits q.k / sqrt(C) of `attn` on the (already normalised) input h."""
+    b, c, hh, ww = h.shape
+    q = attn.q(h).reshape(b, c, hh * ww).permute(0, 2, 1)
+    k = attn.k(h).reshape(b, c, hh * ww)
+    return float((torch.bmm(q, k) * (int(c) ** -0.5)).std())
+
+
+@torch.no_grad()
+def apply_stress(net: nn.Module, seed: int = 0, logit_std: float = 8.0, massive_frac: float = 0.02,
+                 massive_gain: float = 100.0) -> dict:
+    """Trained-like ("stress") statistics for a random-init Decoder / Encoder -- the committed recipe the parity tests and
+    bench.py's `parity.rel_err_vs_oracle_stress` leg use.  Default nn.init gives activations ~ N(0,1), near-uniform softmax rows
+    (logit std ~ 1.5) and no cancellation; the checkpoints the configs name do not look like that (upstream warns of fp16 overflow
+    in its own VAE path: scripts/tilevae.py:21-22, 302-304).  In module order, from one generator:
+      * every conv: weight x g, g log-uniform in [1, 4]; bias ~ N(0, 1);
+      * every 3x3 conv: each third output channel made ZERO-SUM over (cin, ky, kx) -- its result is the difference of large
+        partial sums whenever the (post-SiLU, mostly positive) input has mean >> std;
+      * every GroupNorm: gamma uniform in [0.2, 3], beta uniform in [-2, 2];
+      * mid.block_1.conv2 (writes the residual stream): `massive_frac` of its output channels x `massive_gain` (weights and
+        bias) -- the few huge channels trained auto-encoders carry;
+      * mid.attn_1.q / .k: rescaled so that the scaled logits of a fixed seeded 16x16 latent have std = `logit_std`
+        (8: peaky rows; 16: almost one-hot).
+    Returns what was done (for the bench line / test messages)."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    n_zero_sum = 0
+    for name, m in net.named_modules():
+        if isinstance(m, nn.Conv2d):
+            gain = float(torch.exp(torch.rand((), generator=g) * math.log(4.0)))
+            m.weight.mul_(gain)
+            m.bias.copy_(torch.randn(m.bias.shape, generator=g))
+            if m.kernel_size == (3, 3) and m.out_channels >= 3:
+                m.weight[::3] -= m.weight[::3].mean(dim=(1, 2, 3), keepdim=True)
+                n_zero_sum += len(range(0, m.out_channels, 3))
+        elif isinstance(m, nn.GroupNorm):
+            m.weight.copy_(0.2 + 2.8 * torch.rand(m.weight.shape, generator=g))
+            m.bias.copy_(-2.0 + 4.0 * torch.rand(m.bias.shape, generator=g))
+    info = {"recipe": "stress", "seed": seed, "zero_sum_filters": n_zero_sum}
+    mid = getattr(net, "mid", None)
+    if mid is not None:
+        c2 = mid.block_1.conv2
+        n_massive = max(1, int(round(massive_frac * c2.out_channels)))
+        idx = torch.randperm(c2.out_channels, generator=g)[:n_massive]
+        c2.weight[idx] *= massive_gain
+        c2.bias[idx] *= massive_gain
+        info["massive_channels"] = sorted(int(i) for i in idx)
+        # calibrate the logits on the network's own activations at the attention (fixed seeded probe input)
+        zc = net.conv_in.in_channels
+        probe = torch.randn(1, zc, 16, 16, generator=g)
+        h = net.conv_in(probe)
+        if isinstance(net, Encoder):
+            for lvl in range(net.num_resolutions):
+                for blk in net.down[lvl].block:
+                    h = blk(h)
+                if lvl != net.num_resolutions - 1:
+                    h = net.down[lvl].downsample(h)
+        h = mid.attn_1.norm(mid.block_1(h))
+        s0 = _logit_std(mid.attn_1, h)
+        f = math.sqrt(logit_std / max(s0, 1e-12))
+        for conv in (mid.attn_1.q, mid.attn_1.k):
+            conv.weight.mul_(f)
+            conv.bias.mul_(f)
+        info["logit_std_before"] = round(s0, 3)
+        info["logit_std"] = round(_logit_std(mid.attn_1, h), 3)
+    return info
+
+
+def make_decoder(seed: int = 0, small: bool = False, stress=False, **kw) -> Decoder:
     """Random-weight decoder.  `small=True` gives a CPU-cheap net with the SAME topology (4 levels, attention in the
-    middle, 32-group norms) at ch=32 so that oracle parity tests finish in seconds."""
+    middle, 32-group norms) at ch=32 so that oracle parity tests finish in seconds.  `stress` = True / a logit std
+    (8, 16, ...) applies `apply_stress` (trained-like statistics) on top of the default init; the applied recipe is left in
+    `dec.stress_info`."""
     torch.manual_seed(seed)
     if small:
         kw.setdefault("ch", 32)
     dec = Decoder(**kw).eval()
+    if stress:
+        dec.stress_info = apply_stress(dec, seed, logit_std=8.0 if stress is True else float(stress))
+        for p in dec.parameters():
+            p.requires_grad_(False)
+        return dec
     # default nn.init leaves GroupNorm affine at (1, 0); perturb so a gamma/beta mix-up cannot hide
     g = torch.Generator().manual_seed(seed + 1)
     with torch.no_grad():
@@ -185,11 +261,13 @@ def make_decoder(seed: int = 0, small: bool = False, **kw) -> Decoder:
     return dec
 
 
-def make_encoder(seed: int = 0, small: bool = False, **kw) -> Encoder:
+def make_encoder(seed: int = 0, small: bool = False, stress=False, **kw) -> Encoder:
     torch.manual_seed(seed)
     if small:
         kw.setdefault("ch", 32)
     enc = Encoder(**kw).eval()
+    if stress:
+        enc.stress_info = apply_stress(enc, seed, logit_std=8.0 if stress is True else float(stress))
     for p in enc.parameters():
         p.requires_grad_(False)
     return enc
