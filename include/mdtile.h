@@ -290,6 +290,9 @@ int mdtile_conv2d_gn(const float* d_x, const float* d_coef, const float* d_w_pac
  *                                record image d_y_rec = split(silu(a y + s)) (d_y_coef [B][2][cout]) or split(y) (d_y_coef NULL);
  *                                MDTILE_CONV_UPSAMPLE2X: x_rec is the HALF-size input of the fused nearest-2x upsample conv
  *                                (ldm Upsample, tilevae.py:139-153).  H, W = output size.  d_w_packed: mdtile_conv_pack(ksize 3). */
+#define MDTILE_CONV_REC_ONE_BLOCK 4   /* mdtile_conv2d_rec / mdtile_upconv2d_rec_window flags: name the kernel family instead of letting the */
+#define MDTILE_CONV_REC_TWO_BLOCKS 8  /* launcher choose per launch (one 8-wave block per CU / two 4-wave blocks per CU; identical results) */
+#define MDTILE_CONV_REC_DRIP 16       /* ... / 64-cout items whose epilogue is dripped into the next item's K loop (direct 3x3, cin % 128 == 0) */
 size_t mdtile_rec_size(int B, int C, int H, int W);
 int mdtile_rec_from_f32(const float* d_x, const float* d_coef, void* d_rec, int B, int C, int H, int W, mdtile_stream_t stream);
 int mdtile_rec_to_f32(const void* d_rec, float* d_x, int B, int C, int H, int W, mdtile_stream_t stream);
@@ -307,7 +310,7 @@ int mdtile_conv2d_rec(const void* d_x_rec, const float* d_w_packed, const float*
  *                                image's real neighbours, so the outputs equal the same pixels of the whole-image call bit for bit. */
 int mdtile_upconv2d_rec_window(const void* d_x_rec, const float* d_w_packed, const float* d_bias, float* d_y, void* d_y_rec,
                                const float* d_y_coef, int B, int cin, int cout, int Hin, int Win, const int* y0, const int* x0, int h, int w,
-                               mdtile_stream_t stream);
+                               int flags, mdtile_stream_t stream);
 
 /* Row-band pieces of get_var_mean (tilevae.py:207-215) for an activation that is split by rows across GPUs (sequence-parallel
  * fast-mode estimator): every plane holds plane_stride floats of which [offset, offset+len) are this rank's own rows.

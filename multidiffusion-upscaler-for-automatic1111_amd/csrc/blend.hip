@@ -448,7 +448,7 @@ int launch_blend(const BlendParams& P, int method, bool finalize, hipStream_t s)
         int pp = 8, g = 2;
         while (pp > 1 && work / pp < 131072) pp >>= 1;
         if (pp < 8) g = 4;
-        if (const char* e = getenv("MDTILE_BLEND_CFG")) {  // probing override; "0,0" keeps the heuristic
+        if (const char* e = probe_env("MDTILE_BLEND_CFG")) {  // probes build only; "0,0" keeps the heuristic
             int epp = 0, eg = 0;
             if (sscanf(e, "%d,%d", &epp, &eg) == 2 && epp > 0 && eg > 0) { pp = epp; g = eg; }
         }

@@ -13,6 +13,18 @@
 
 namespace mdt {
 
+// Probe scaffolding (environment switches that re-shape launches, make kernels skip their stores or hand them a stamp buffer) exists
+// only in the PROBES build of the library (mdtile/build.py: build_probes() -> probes/_ab/libmdtile_probes.so, -DMDTILE_PROBES=1; the
+// scripts under probes/ ask for it).  The shipping library is compiled with -DMDTILE_PROBES=0: probe_env() is the constant nullptr
+// there, so no probe switch is read, none of their names is in the binary, and no launch path calls getenv.  The user-facing
+// switches (MDTILE_CONV_MODE, MDTILE_ATTN_MODE, MDTILE_SHARD_TRANSPORT) are read ONCE, when the library is loaded / a context is made.
+constexpr bool kProbes = MDTILE_PROBES != 0;
+template <bool P = kProbes>
+static inline const char* probe_env(const char* name) {
+    if constexpr (P) return getenv(name);
+    else return nullptr;
+}
+
 void set_error(const char* fmt, ...);
 bool conv_strict_f32();   // mdtile_set_precision / MDTILE_CONV_MODE=f32: every conv on the exact-fp32 MFMA kernels
 bool attn_strict_f32();   // ... / MDTILE_ATTN_MODE=f32: attention on the exact-fp32 kernel

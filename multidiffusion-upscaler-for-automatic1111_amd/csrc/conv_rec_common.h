@@ -37,7 +37,8 @@ struct ConvRParams {
     int ptiles, PX, NCB, NK;  // pixel tiles, tiles per row, cout blocks, 16-channel K-steps
     // two-blocks-per-CU kernels (vae_conv_rec2.hip) only:
     unsigned skew_ticks;      // start-up delay (100 MHz ticks) of the block that arrives SECOND on its CU: puts the pair half an item out of phase
-    unsigned* cu_ctr;         // [8 XCDs x 256 hardware CU ids] arrival counters (never reset: only the parity is used); null = skew by block index
+    unsigned* cu_ctr;         // [16 XCC ids x 256 hardware CU ids] arrival counters, word = launch epoch << 8 | blocks of that launch seen on the CU; null = skew by block index
+    unsigned epoch;           // this launch's epoch (24 bits, host counter per device): a counter word of another epoch restarts at 0
     unsigned* census;         // probing: [gridDim.x] hardware id of the CU each block ran on | arrival parity << 31, or null
     int dbg;                  // probing (MDTILE_REC_DBG): bit 0 = skip the epilogue (K loop only: nothing is written); bit 3 = block 0 of the
                               // one-block kernel writes s_memtime stamps per wave and item to `census` (probes/conv_item_timeline.py)
@@ -49,6 +50,9 @@ namespace {
 
 using mdt::ConvRParams;
 using mdt::REC_WIN_MAXB;
+
+// ConvRParams::dbg as the kernels see it: the constant 0 in the shipping library (common.h: kProbes) -- every probe branch folds away
+__device__ __forceinline__ int pdbg(int d) { return mdt::kProbes ? d : 0; }
 
 __device__ __forceinline__ void split8r(const float (&v)[8], u32x4& hi, u32x4& lo) {
     bf16x8 h, l;

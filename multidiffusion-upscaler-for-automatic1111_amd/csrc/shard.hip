@@ -316,13 +316,40 @@ extern "C" int mdtile_shard_probe_rank(int nranks, int rank, const void* id128, 
     ncclResult_t r = R->CommInitRankConfig(&comm, nranks, id, rank, &cfg);
     const auto t0 = std::chrono::steady_clock::now();
     bool timed_out = false;
-    while (r == ncclInProgress || (r == ncclSuccess && comm)) {
-        ncclResult_t st = ncclSuccess;
-        if (comm && R->CommGetAsyncError(comm, &st) != ncclSuccess) { r = ncclInternalError; break; }
-        r = st;
-        if (st != ncclInProgress) break;
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) { timed_out = true; break; }
-        std::this_thread::sleep_for(std::chrono::milliseconds(2));
+    auto late = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s; };
+    // OK is reported only after ncclCommGetAsyncError has said ncclSuccess on a NON-NULL communicator; "in progress" without a
+    // communicator handle cannot be polled and counts as a failure
+    auto settle = [&](ncclResult_t first) -> ncclResult_t {
+        if (first != ncclInProgress && first != ncclSuccess) return first;
+        if (!comm) return ncclInternalError;
+        while (true) {
+            ncclResult_t st = ncclSuccess;
+            if (R->CommGetAsyncError(comm, &st) != ncclSuccess) return ncclInternalError;
+            if (st != ncclInProgress) return st;
+            if (late()) { timed_out = true; return ncclInProgress; }
+            std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        }
+    };
+    r = settle(r);
+    // Handshake before the probe communicator is thrown away: one 4-byte all-reduce completes on this rank only when EVERY rank has
+    // finished its own bring-up and joined -- without it a rank that comes up early would abort the communicator while slower peers
+    // are still polling their init on it.
+    hipStream_t hs = nullptr;
+    int* d_one = nullptr;
+    if (r == ncclSuccess && !timed_out) {
+        if (hipStreamCreateWithFlags(&hs, hipStreamNonBlocking) != hipSuccess || hipMalloc(&d_one, sizeof(int)) != hipSuccess ||
+            hipMemsetAsync(d_one, 0, sizeof(int), hs) != hipSuccess) {
+            r = ncclInternalError;
+        } else {
+            r = settle(R->AllReduce(d_one, d_one, 1, ncclInt32, ncclSum, comm, hs));
+            while (r == ncclSuccess && !timed_out) {
+                const hipError_t q = hipStreamQuery(hs);
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) { r = ncclInternalError; break; }
+                if (late()) { timed_out = true; break; }
+                std::this_thread::sleep_for(std::chrono::milliseconds(2));
+            }
+        }
     }
     int rc = MDTILE_OK;
     if (timed_out || r != ncclSuccess) {
@@ -330,7 +357,9 @@ extern "C" int mdtile_shard_probe_rank(int nranks, int rank, const void* id128, 
                             : "mdtile_shard_probe_rank: communicator bring-up failed (nranks %d, %.1f s budget, rank %d)", nranks, timeout_s, rank);
         rc = MDTILE_E_HIP;
     }
-    if (comm) (void)R->CommAbort(comm);      // success or not: the probe communicator is not kept (abort = destroy without a final handshake)
+    if (comm) (void)R->CommAbort(comm);      // success or not: the probe communicator is not kept (abort also cancels a handshake still in flight)
+    if (d_one) (void)hipFree(d_one);
+    if (hs) (void)hipStreamDestroy(hs);
     (void)hipSetDevice(cur);
     return rc;
 }

@@ -486,7 +486,7 @@ static int attn_num_cus() {
     return n;
 }
 static int attn_nsplit(int B, int Tq, int Tk) {
-    static const int forced = [] { const char* e = getenv("MDTILE_ATTN_SPLIT"); return e ? atoi(e) : 0; }();
+    static const int forced = [] { const char* e = probe_env("MDTILE_ATTN_SPLIT"); return e ? atoi(e) : 0; }();
     const int nkb = (Tk + 127) / 128;
     if (forced >= 1 && forced <= 4) return forced <= nkb ? forced : 1;
     // The split is chosen for ONE image of the batch, whatever B is: the key ranges fix the order in which a query's partial sums are

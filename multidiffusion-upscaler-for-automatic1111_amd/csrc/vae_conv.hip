@@ -244,7 +244,7 @@ size_t rec_plane_records(int H, int W);
 int rec_from_f32_launch(const float* d_x, const float* d_coef, void* d_rec, int B, int C, int H, int W, hipStream_t s);
 int rec_to_f32_launch(const void* d_rec, float* d_x, int B, int C, int H, int W, hipStream_t s);
 int conv_rec_launch(const void* d_xrec, const void* d_w_rec, const float* d_bias, const float* d_res, float* d_y32, void* d_yrec,
-                    const float* d_ycoef, int B, int cin, int cout, int H, int W, int up, hipStream_t s, const int* win = nullptr);
+                    const float* d_ycoef, int B, int cin, int cout, int H, int W, int up, hipStream_t s, const int* win = nullptr, int family = 0);
 // vae_conv1x1_bf16x3.hip
 bool conv1x1_bf16x3_eligible(int cout, int cin);
 size_t conv1x1_bf16x3_packed_floats(int cout, int cin);
@@ -357,6 +357,9 @@ extern "C" int mdtile_conv2d_rec_supported(int cout, int cin, int ksize, int fla
     return conv_rec_supported(cout, cin, ksize) ? 1 : 0;
 }
 
+// MDTILE_CONV_REC_ONE_BLOCK / _TWO_BLOCKS: the caller names the kernel family (tests, probes); 0 = chosen per launch (rec_two_blocks)
+static int rec_family(int flags) { return (flags & MDTILE_CONV_REC_ONE_BLOCK) ? 1 : (flags & MDTILE_CONV_REC_TWO_BLOCKS) ? 2 : (flags & MDTILE_CONV_REC_DRIP) ? 3 : 0; }
+
 extern "C" int mdtile_conv2d_rec(const void* d_x_rec, const float* d_w_packed, const float* d_bias, const float* d_residual, float* d_y,
                                  void* d_y_rec, const float* d_y_coef, int B, int cin, int cout, int H, int W, int flags,
                                  mdtile_stream_t stream) {
@@ -369,13 +372,13 @@ extern "C" int mdtile_conv2d_rec(const void* d_x_rec, const float* d_w_packed, c
     MDT_CHECK_ARG(cout % 128 == 0 || (!up && !d_y_rec && !d_residual),
                   "mdtile_conv2d_rec: the narrow (cout < 32) kernel writes fp32 only, no residual, no upsample (cout=%d)", cout);
     return conv_rec_launch(d_x_rec, d_w_packed + f32_packed_floats(cout, cin, 3), d_bias, d_residual, d_y, d_y_rec, d_y_coef, B, cin, cout,
-                           H, W, up, as_stream(stream));
+                           H, W, up, as_stream(stream), nullptr, rec_family(flags));
 }
 
 // Nearest-2x + 3x3 conv of a WINDOW of the input record image (live-window narrowing of the decoder tiles, see include/mdtile.h)
 extern "C" int mdtile_upconv2d_rec_window(const void* d_x_rec, const float* d_w_packed, const float* d_bias, float* d_y, void* d_y_rec,
                                           const float* d_y_coef, int B, int cin, int cout, int Hin, int Win, const int* y0, const int* x0,
-                                          int h, int w, mdtile_stream_t stream) {
+                                          int h, int w, int flags, mdtile_stream_t stream) {
     MDT_CHECK_ARG(d_x_rec && d_w_packed && (d_y || d_y_rec) && y0 && x0, "mdtile_upconv2d_rec_window: null argument (one of d_y / d_y_rec is required)");
     MDT_CHECK_ARG(mdtile_conv2d_rec_supported(cout, cin, 3, 0) && cout % 128 == 0, "mdtile_upconv2d_rec_window: no record kernel for cout=%d cin=%d", cout, cin);
     MDT_CHECK_ARG(B >= 1, "mdtile_upconv2d_rec_window: B=%d", B);
@@ -394,7 +397,7 @@ extern "C" int mdtile_upconv2d_rec_window(const void* d_x_rec, const float* d_w_
     MDT_CHECK_ARG(rec_image_ok(B, cin, Hin, Win) && rec_image_ok(B, cout, 2 * h, 2 * w),
                   "mdtile_upconv2d_rec_window: unsupported shape B=%d cin=%d cout=%d Hin=%d Win=%d", B, cin, cout, Hin, Win);
     return conv_rec_launch(d_x_rec, d_w_packed + f32_packed_floats(cout, cin, 3), d_bias, nullptr, d_y, d_y_rec, d_y_coef, B, cin, cout,
-                           2 * h, 2 * w, 1, as_stream(stream), win);
+                           2 * h, 2 * w, 1, as_stream(stream), win, rec_family(flags));
 }
 
 // ldm Downsample: y = conv3x3_stride2(pad(x, right 1, bottom 1)); output (Hin - 2) / 2 + 1 rows (likewise columns).

@@ -409,9 +409,9 @@ namespace mdt {
 bool conv1x1_bf16x3_eligible(int cout, int cin) { return cin % 32 == 0 && cout >= 32; }
 // couts per block: 256 (one pass over the input for cout % 256 == 0), 128, or 64 for the small decoders' narrow convs
 static int conv1x1_mt(int cout) { return cout > 128 ? 8 : (cout > 64 ? 4 : 2); }
-// MDTILE_C1X1_STREAM=0 (probing, read per launch): keep the plain kernel on the wide images too
+// MDTILE_C1X1_STREAM=0 (probes build only, read per launch): keep the plain kernel on the wide images too
 static bool conv1x1_stream_on() {
-    const char* e = getenv("MDTILE_C1X1_STREAM");
+    const char* e = probe_env("MDTILE_C1X1_STREAM");
     return !(e && e[0] == '0');
 }
 

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rec(const ConvRParams P) {
 
     // probing (MDTILE_REC_DBG bit 3 + MDTILE_REC_STAMPS=<device address>): block 0 records s_memtime per wave and item at
     //   0 item start (behind the barrier) | 1 K loop done | 2 epilogue code done (stores issued) | 4 vmcnt(0) + barrier of the next item passed
-    unsigned long long* const stamps = (P.dbg & 8) && P.census && blockIdx.x == 0 ? reinterpret_cast<unsigned long long*>(P.census) : nullptr;
+    unsigned long long* const stamps = (pdbg(P.dbg) & 8) && P.census && blockIdx.x == 0 ? reinterpret_cast<unsigned long long*>(P.census) : nullptr;
     int item_no = 0;
     auto stamp = [&](int k) {
         if (stamps && lane == 0 && item_no < 64) stamps[(item_no * 8 + wave) * 8 + k] = __builtin_readcyclecounter();
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rec(const ConvRParams P) {
     // a conv2's residual arrives in the accumulators (conv_rec_common.h: ResRows): the first item's rows are requested here, every later
     // item's by the epilogue of the item before it
     f32x16 acc[MW][NROW][1];
-    const bool res_in_acc = P.res != nullptr && !(P.dbg & 1);
+    const bool res_in_acc = P.res != nullptr && !(pdbg(P.dbg) & 1);
     auto res_rows = [&](const WorkItem& it, bool on) {
         ResRows<NROW> R;
         R.on = on; R.b = it.b; R.mt_global0 = it.cb * MT + wm * MW;
@@ -300,14 +300,14 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rec(const ConvRParams P) {
         E.has_bias = P.bias != nullptr; E.has_act = P.yrec != nullptr && P.coef != nullptr;
         E.Cout = P.Cout; E.H = P.H; E.W = P.W; E.b = cur.b; E.kg = kg;
         E.HW = (size_t)P.H * P.W; E.planeO = plane; E.WpO = Wp;
-        E.dbg = P.dbg;
+        E.dbg = pdbg(P.dbg);
         int le = lane;
         asm volatile("" : "+v"(le));      // (re-derived: a separate l31 kept alive through the epilogue goes to scratch)
         const int x = cur.x0 + (le & 31);
         int ys[NROW];
 #pragma unroll
         for (int n = 0; n < NROW; ++n) ys[n] = cur.y0 + wr * NROW + n;
-        if (!(P.dbg & 1)) {
+        if (!(pdbg(P.dbg) & 1)) {
             epilogue_item<1, NROW, MW>(E, ec_l + par * EC_REC, acc, wm * MW, cur.cb * MT + wm * MW, ys, x, x < P.W, res_rows(nxt, work_n < total));
         }
         stamp(2);
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(512, 2) void k_upconv_rec(const ConvRParams P) {
         E.res = P.res; E.y32 = P.y32; E.yrec = P.yrec;
         E.has_bias = P.bias != nullptr; E.has_act = P.yrec != nullptr && P.coef != nullptr;
         E.Cout = P.Cout; E.H = P.H; E.W = P.W; E.b = cur.b; E.kg = kg;
-        E.HW = (size_t)P.H * P.W; E.planeO = (size_t)(P.H + 2) * rec_pitch(P.W); E.WpO = rec_pitch(P.W); E.dbg = P.dbg;
+        E.HW = (size_t)P.H * P.W; E.planeO = (size_t)(P.H + 2) * rec_pitch(P.W); E.WpO = rec_pitch(P.W); E.dbg = pdbg(P.dbg);
         const int xi = cur.x0 + l31;
         int ys[NROW];
 #pragma unroll
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(512, 2) void k_upconv_rec(const ConvRParams P) {
             const int yi = cur.y0 + wr * NROW + n;
             ys[n] = yi < P.Hin ? 2 * yi + cur.a : P.H;      // rows past the input's last row: marked invalid
         }
-        if (!(P.dbg & 1)) {
+        if (!(pdbg(P.dbg) & 1)) {
             epilogue_item<2, NROW, MW>(E, ec_l + par * EC_REC, acc, wm * MW, cur.cb * MT + wm * MW, ys, 2 * xi, xi < P.Win, ResRows<NROW>{});
         }
         if (work_n >= total) break;
@@ -598,17 +598,17 @@ namespace mdt {
 
 size_t conv_bf16x3_direct_records(int cout, int cin);   // vae_conv_bf16x3.hip
 
-// MDTILE_REC_PERSIST=0: one item per block (A/B of the persistent schedule; read per launch so a probe can flip it in-process)
+// MDTILE_REC_PERSIST=0 (probes build only): one item per block (A/B of the persistent schedule; read per launch so a probe can flip it in-process)
 constexpr int REC_STAGGER_PCT_DEFAULT = 0;      // off: -2 ... -5 % on single conv1 launches (profiles/r4u, r4v), nothing on the 8K decode (profiles/r4y: 1869 / 1870 vs 1870 / 1874 ms)
 
 static bool rec_persistent() {
-    const char* e = getenv("MDTILE_REC_PERSIST");
+    const char* e = probe_env("MDTILE_REC_PERSIST");
     return !(e && e[0] == '0');
 }
 
 // MDTILE_REC_GRID=n: probing -- the persistent kernels run as if the chip had n CUs (n % 8 == 0)
 static int num_cus() {
-    if (const char* e = getenv("MDTILE_REC_GRID")) {
+    if (const char* e = probe_env("MDTILE_REC_GRID")) {
         const int n = atoi(e);
         if (n >= 8) return n / 8 * 8;
     }
@@ -624,6 +624,9 @@ static int num_cus() {
 
 // vae_conv_rec2.hip: the two-blocks-per-CU form of the cout % 128 == 0 kernels
 int conv_rec2_launch(ConvRParams P, int B, int up, hipStream_t s, int cus);
+// vae_conv_recd.hip: 64-cout items with the epilogue dripped into the next item's K loop (direct 3x3, cin % 128 == 0)
+bool conv_recd_supported(int cout, int cin);
+int conv_recd_launch(ConvRParams P, int B, hipStream_t s, int cus);
 
 // Which kernel family takes a launch.  The two-blocks-per-CU kernels (vae_conv_rec2.hip) lose 3-12 % on launches that fill the chip many
 // times over (profiles/r4a: their 8-row items double the weight stream through the CU's memory pipe and the store epilogue is not
@@ -632,9 +635,11 @@ int conv_rec2_launch(ConvRParams P, int B, int up, hipStream_t s, int cus);
 // Cost model, in units of one 16-row item on a CU of its own (fitted on profiles/r4d/conv_two_blocks_small_launches.log):
 //   one block / CU:   ceil(items16 / CUs)
 //   two blocks / CU:  full rounds of 2 CUs items cost `pair`; a last round of <= CUs items (each block alone on its CU) costs `lone`
-// MDTILE_REC_BLOCKS=1 / 2 forces a family (A/B in probes/conv_rec2_ab.py; read per launch).
-static bool rec_two_blocks(long long items16, long long items8, int cus, int up) {
-    if (const char* e = getenv("MDTILE_REC_BLOCKS")) {
+// family = 1 / 2 (MDTILE_CONV_REC_ONE_BLOCK / _TWO_BLOCKS in the call's flags) names the family (tests, A/B in probes/conv_rec2_ab.py).
+static bool rec_two_blocks(long long items16, long long items8, int cus, int up, int family) {
+    if (family == 1) return false;
+    if (family == 2) return true;
+    if (const char* e = probe_env("MDTILE_REC_BLOCKS")) {      // (probes build only: the old in-process A/B switch of the scripts under probes/)
         if (e[0] == '1') return false;
         if (e[0] == '2') return true;
     }
@@ -668,7 +673,7 @@ int rec_to_f32_launch(const void* d_rec, float* d_x, int B, int C, int H, int W,
 // win (sub-pixel upsample kernel only, else null): {HinF, WinF, y0[0], x0[0], ..., y0[7], x0[7]} -- d_xrec is the record image of
 // [B, cin, HinF, WinF] and image b's conv reads its window [y0[b & 7] : .. + H/2, x0[b & 7] : .. + W/2]  (all 8 slots filled)
 int conv_rec_launch(const void* d_xrec, const void* d_w_rec, const float* d_bias, const float* d_res, float* d_y32, void* d_yrec,
-                    const float* d_ycoef, int B, int cin, int cout, int H, int W, int up, hipStream_t s, const int* win) {
+                    const float* d_ycoef, int B, int cin, int cout, int H, int W, int up, hipStream_t s, const int* win, int family) {
     ConvRParams P;
     P.x = (const u32x4*)d_xrec; P.w = (const u32x4*)d_w_rec; P.bias = d_bias; P.res = d_res; P.y32 = d_y32;
     P.yrec = (u32x4*)d_yrec; P.coef = d_ycoef;
@@ -681,25 +686,26 @@ int conv_rec_launch(const void* d_xrec, const void* d_w_rec, const float* d_bias
     }
     P.NCB = cout % 128 == 0 ? cout / 128 : 1;
     P.NK = cin / 16;
-    P.skew_ticks = 0; P.cu_ctr = nullptr; P.census = nullptr;
+    P.skew_ticks = 0; P.cu_ctr = nullptr; P.census = nullptr; P.epoch = 0;
     P.dbg = 0;
-    if (const char* e = getenv("MDTILE_REC_DBG")) P.dbg = atoi(e);      // probing only (probes/conv_rec_diag.py, conv_item_timeline.py): see ConvRParams::dbg
+    if (const char* e = probe_env("MDTILE_REC_DBG")) P.dbg = atoi(e);      // probing only (probes/conv_rec_diag.py, conv_item_timeline.py): see ConvRParams::dbg
     if (P.dbg & 8)
-        if (const char* e = getenv("MDTILE_REC_STAMPS")) P.census = reinterpret_cast<unsigned*>((uintptr_t)strtoull(e, nullptr, 16));
+        if (const char* e = probe_env("MDTILE_REC_STAMPS")) P.census = reinterpret_cast<unsigned*>((uintptr_t)strtoull(e, nullptr, 16));
     if (up) P.w = (const u32x4*)d_w_rec + conv_bf16x3_direct_records(cout, cin);
+    if (family == 3 && !up && conv_recd_supported(cout, cin)) return conv_recd_launch(P, B, s, num_cus());
     if (cout % 128 == 0 && rec_persistent()) {
         const int cus = num_cus() / 8 * 8;
         const int hin = up ? P.Hin : H, win = up ? P.Win : W, per = P.NCB * (up ? 2 : 1);      // items tile the INPUT grid of the sub-pixel form
         const long long px = (win + 31) / 32;
         const long long items16 = (px * ((hin + (up ? 7 : 15)) / (up ? 8 : 16)) + 7) / 8 * 8 * per * B;
         const long long items8 = (px * ((hin + (up ? 3 : 7)) / (up ? 4 : 8)) + 7) / 8 * 8 * per * B;
-        if (rec_two_blocks(items16, items8, cus, up)) return conv_rec2_launch(P, B, up, s, num_cus());
+        if (rec_two_blocks(items16, items8, cus, up, family)) return conv_rec2_launch(P, B, up, s, num_cus());
     }
     // start-up stagger (stagger_start): spread = MDTILE_REC_STAGGER_PCT percent of an estimated item period, launches of >= 6 rounds only
     // default: a quarter period for launches that write records ONLY (a conv1: -2 ... -5 % per launch, profiles/r4u, r4v; launches with an fp32
     // stream run at their CU's own memory-pipe floor either way and only pay the late end)
     auto stagger = [&](long long items, int cus, unsigned period_ticks) {
-        const char* e = getenv("MDTILE_REC_STAGGER_PCT");      // (read per launch: probes/conv_stagger_ab.py switches it between launches)
+        const char* e = probe_env("MDTILE_REC_STAGGER_PCT");      // (read per launch: probes/conv_stagger_ab.py switches it between launches)
         const int p = e ? atoi(e) : ((!d_y32 && !d_res) ? REC_STAGGER_PCT_DEFAULT : 0);
         P.skew_ticks = (rec_persistent() && items >= 6LL * cus && p > 0) ? period_ticks * (unsigned)p / 100u : 0u;
     };

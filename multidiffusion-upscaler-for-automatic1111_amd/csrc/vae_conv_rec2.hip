@@ -29,6 +29,8 @@
 // :218-245 custom_group_norm, :102-104 SiLU, :614-616 add_res).
 #include "common.h"
 
+#include <mutex>
+
 using namespace mdt;
 
 #include "conv_rec_common.h"
@@ -60,8 +62,19 @@ __device__ __forceinline__ void startup_skew(const ConvRParams& P, int wave, int
     const unsigned key = (xcc << 8) | ((hw >> 8) & 255u);
     unsigned second = blockIdx.x >= gridDim.x / 2 ? 1u : 0u;
     if (P.cu_ctr) {
+        // arrival number of this block on its CU IN THIS LAUNCH: the counter word carries the launch epoch, so a launch that left an odd
+        // number of blocks on some CUs (grid < 2 CUs is common for this family) cannot flip the parity of every later launch there
         unsigned n = 0;
-        if (lane == 0) n = atomicAdd(P.cu_ctr + key, 1u);
+        if (lane == 0) {
+            unsigned* c = P.cu_ctr + key;
+            unsigned seen = *reinterpret_cast<volatile unsigned*>(c);
+            while (true) {
+                const unsigned cnt = (seen >> 8) == P.epoch ? (seen & 255u) : 0u;
+                const unsigned prev = atomicCAS(c, seen, (P.epoch << 8) | ((cnt + 1u) & 255u));
+                if (prev == seen) { n = cnt; break; }
+                seen = prev;
+            }
+        }
         second = (unsigned)__builtin_amdgcn_readfirstlane((int)n) & 1u;
     }
     if (P.census && lane == 0) P.census[blockIdx.x] = key | (second << 31);
@@ -196,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_rec2(const ConvRParams P) {
 
     // a conv2's residual arrives in the accumulators, as in k_conv3x3_rec (conv_rec_common.h: ResRows)
     f32x16 acc[MW][NROW][1];
-    const bool res_in_acc = P.res != nullptr && !(P.dbg & 1);
+    const bool res_in_acc = P.res != nullptr && !(pdbg(P.dbg) & 1);
     auto res_rows = [&](const Item2& it, bool on) {
         ResRows<NROW> R;
         R.on = on; R.b = it.b; R.mt_global0 = it.cb * MT + wm * MW;
@@ -316,14 +329,14 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_rec2(const ConvRParams P) {
         E.res = P.res; E.y32 = P.y32; E.yrec = P.yrec;
         E.has_bias = P.bias != nullptr; E.has_act = P.yrec != nullptr && P.coef != nullptr;
         E.Cout = P.Cout; E.H = P.H; E.W = P.W; E.b = cur.b; E.kg = kg;
-        E.HW = (size_t)P.H * P.W; E.planeO = plane; E.WpO = Wp; E.dbg = P.dbg;
+        E.HW = (size_t)P.H * P.W; E.planeO = plane; E.WpO = Wp; E.dbg = pdbg(P.dbg);
         int le = lane;
         asm volatile("" : "+v"(le));      // (re-derived: a separate l31 kept alive through the epilogue goes to scratch)
         const int x = cur.x0 + (le & 31);
         int ys[NROW];
 #pragma unroll
         for (int n = 0; n < NROW; ++n) ys[n] = cur.y0 + wr * NROW + n;
-        if (!(P.dbg & 1)) {
+        if (!(pdbg(P.dbg) & 1)) {
             epilogue_item<1, NROW, MW, 32>(E, ec_l + par * EC2, acc, wm * MW, cur.cb * MT + wm * MW, ys, x, x < P.W, res_rows(nxt, has_next));
         }
         if (!has_next) break;
@@ -562,7 +575,7 @@ __global__ __launch_bounds__(256, 2) void k_upconv_rec2(const ConvRParams P) {
         E.res = P.res; E.y32 = P.y32; E.yrec = P.yrec;
         E.has_bias = P.bias != nullptr; E.has_act = P.yrec != nullptr && P.coef != nullptr;
         E.Cout = P.Cout; E.H = P.H; E.W = P.W; E.b = cur.b; E.kg = kg;
-        E.HW = (size_t)P.H * P.W; E.planeO = (size_t)(P.H + 2) * rec_pitch(P.W); E.WpO = rec_pitch(P.W); E.dbg = P.dbg;
+        E.HW = (size_t)P.H * P.W; E.planeO = (size_t)(P.H + 2) * rec_pitch(P.W); E.WpO = rec_pitch(P.W); E.dbg = pdbg(P.dbg);
         const int xi = cur.x0 + l31;
         int ys[NROW];
 #pragma unroll
@@ -570,7 +583,7 @@ __global__ __launch_bounds__(256, 2) void k_upconv_rec2(const ConvRParams P) {
             const int yi = cur.y0 + wr * NROW + n;
             ys[n] = yi < P.Hin ? 2 * yi + cur.a : P.H;      // rows past the input's last row: marked invalid
         }
-        if (!(P.dbg & 1)) {
+        if (!(pdbg(P.dbg) & 1)) {
             epilogue_item<2, NROW, MW, 32>(E, ec_l + par * EC2, acc, wm * MW, cur.cb * MT + wm * MW, ys, 2 * xi, xi < P.Win, ResRows<NROW>{});
         }
         if (!has_next) break;
@@ -587,33 +600,41 @@ __global__ __launch_bounds__(256, 2) void k_upconv_rec2(const ConvRParams P) {
 
 namespace mdt {
 
-// arrival counters of startup_skew: one buffer per device, allocated on first use, zeroed once and never reset
-static unsigned* cu_counters() {
+// arrival counters of startup_skew: one buffer per device, allocated on first use (under a lock: launches may come from several host
+// threads), zeroed once; every launch takes a fresh epoch (see startup_skew), so nothing is ever reset
+static unsigned* cu_counters(unsigned* epoch) {
+    static std::mutex mu;
     static unsigned* buf[64] = {};
+    static unsigned next_epoch[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
     if (!buf[dev]) {
         unsigned* p = nullptr;
         if (hipMalloc(&p, 16 * 256 * sizeof(unsigned)) != hipSuccess) return nullptr;
         if (hipMemset(p, 0, 16 * 256 * sizeof(unsigned)) != hipSuccess) return nullptr;
         buf[dev] = p;
     }
+    next_epoch[dev] = (next_epoch[dev] + 1u) & 0xFFFFFFu;
+    if (next_epoch[dev] == 0u) next_epoch[dev] = 1u;      // (0 = the zeroed buffer's epoch)
+    *epoch = next_epoch[dev];
     return buf[dev];
 }
 
-// Probing switches (read per launch so that a probe can flip them in-process):
+// Probing switches (PROBES build of the library only -- common.h: probe_env; read per launch so that a probe can flip them in-process):
 //   MDTILE_REC2_SKEW    0 = no start-up delay, 1 = by block index (>= grid / 2), 2 = by the per-CU arrival counter (default)
 //   MDTILE_REC2_SKEW_PCT  the delay as a percentage of an item's K loop at one block per CU-half (default 100)
 //   MDTILE_REC2_CENSUS  device address (hex) of a [grid] unsigned buffer that receives every block's hardware CU id
 int conv_rec2_launch(ConvRParams P, int B, int up, hipStream_t s, int cus) {
     int skew = 2, pct = 100;
-    if (const char* e = getenv("MDTILE_REC2_SKEW")) skew = atoi(e);
-    if (const char* e = getenv("MDTILE_REC2_SKEW_PCT")) pct = atoi(e);
+    if (const char* e = probe_env("MDTILE_REC2_SKEW")) skew = atoi(e);
+    if (const char* e = probe_env("MDTILE_REC2_SKEW_PCT")) pct = atoi(e);
     P.census = nullptr;
-    if (const char* e = getenv("MDTILE_REC2_CENSUS")) P.census = reinterpret_cast<unsigned*>((uintptr_t)strtoull(e, nullptr, 16));
-    P.cu_ctr = skew == 2 ? cu_counters() : nullptr;
+    if (const char* e = probe_env("MDTILE_REC2_CENSUS")) P.census = reinterpret_cast<unsigned*>((uintptr_t)strtoull(e, nullptr, 16));
+    P.epoch = 0;
+    P.cu_ctr = skew == 2 ? cu_counters(&P.epoch) : nullptr;
     int per_cu = 2;                                   // two blocks per CU
-    if (const char* e = getenv("MDTILE_REC2_PER_CU")) per_cu = atoi(e) == 1 ? 1 : 2;      // probing: a 4-wave block alone on its CU
+    if (const char* e = probe_env("MDTILE_REC2_PER_CU")) per_cu = atoi(e) == 1 ? 1 : 2;      // probing: a 4-wave block alone on its CU
     const int grid_max = per_cu * (cus / 8 * 8);
     if (up) {
         // K loop of one item with the SIMDs to itself: NK x 8 steps x 12 MFMAs x 32 clk at ~2 GHz = NK x 1.5 us; in 10 ns ticks

@@ -1,0 +1,479 @@
+// Record-image 3x3 conv with a DRIPPED (software-pipelined) epilogue  (round 5).
+//
+// Same arithmetic, record images, packed weights and per-accumulator MFMA order as vae_conv_rec.hip (results bit-identical to
+// k_conv3x3_rec<2,2,4>); what changes is WHEN an item's results leave the CU.  There an item's 8 waves finish their K loop
+// together and then spend 14-46 k cycles (record / fp32 + records + residual) issuing bias, activation, split and stores with the
+// matrix cores idle: the CU's vector-memory pipe is ONE in-order queue that retires ~27 B/clk of stores (DESIGN.md section 3,
+// "Late round 4"), a conv2 item moves 768 KB through it, and since gfx9 counts stores in vmcnt the next item's operand DMA waits
+// sit behind them.  Two resident blocks did not hide it either (vae_conv_rec2.hip: the other block's DMA queues behind the same
+// stores).  What was never tried is to keep the stores from piling up at all:
+//
+//   * a wave holds TWO accumulator sets: `acc` (the item whose K loop is running) and `sealed` (the results of the block's
+//     PREVIOUS item).  Item i-1's bias / fp32 stores / activation / split / record stores and the residual loads of item i+1 are
+//     issued in SLOTS of <= 4 KB per wave between the K-steps of item i -- at most one slot per phase, never in a phase that also
+//     requests an input stage -- so the memory pipe sees ~7 B/clk of epilogue traffic next to ~11 B/clk of operand DMA and never
+//     queues; the slot's VALU work (2 transcendentals per value) runs in the issue slack a wave has beside the MFMAs of the wave
+//     it shares its SIMD with (waves w and w + 4 take their slots one step apart).
+//   * both sets have to fit the 256-register budget of two waves per SIMD next to two fragment sets: 64 + 64 accumulator
+//     registers = four 32x32 tiles each.  The item is therefore 64 couts x 16 rows x 32 px (wave tile 64 couts x 2 rows), HALF
+//     the couts of k_conv3x3_rec's item on the same 18-row input stage: the input stream from L2 doubles per MFMA, the weight
+//     stream halves (9.5 vs 7.1 KB of DMA per K-step and 16 rows: 1.35x -- the row-halved items of vae_conv_rec2.hip pay 1.69x).
+//   * at the item boundary the two sets change roles (64 register swaps per wave); the residual of a conv2 is loaded into the
+//     sealed registers right after they were stored from, so the next K loop starts from it: y = (res + sum) + bias as before.
+//   * the block's LAST item has no K loop to hide under: its epilogue runs in one piece (1 item in ~70).
+//
+// K loop: the protocol of k_conv3x3_rec -- phases (K-step k, tap row dy) of three steps dx (12 MFMAs per wave and step), input
+// stage [hl][kg][18][34] records x 2, weight chunks [hl][dx][mt 2][lane] (12 KB) in a 3-slot ring (slot = dy), ONE barrier per
+// phase behind its dx = 0 step, chunk ph + 2 and the next K-step's input requested behind the barrier, the next item's first
+// operands in the item's last phase.  One trip = 4 K-steps = 12 phases = 36 steps, fully unrolled (cin % 64 == 0).  The 8 slots of an
+// item sit in the dy = 1 / dy = 2 phases of its FIRST trip, position i = 2 k + dy - 1, for the wave's four (m-tile, row) units u = i / 2:
+//     i even: + bias, fp32 stores, activation + split + record stores of channels 0-7 of the lane's 16
+//     i odd : the same for channels 8-15, then the residual row of item i+1 into the unit's registers
+// (cin = 128: the second trip is left for the last residual row to land; the code of a trip stays ~40 KB).
+// vmcnt (gfx9 counts loads AND stores in it, in order): a phase's site issues chunk ph + 2 FIRST and its slot's stores / loads
+// AFTER it, and the wait in front of the next barrier is vmcnt(N), N = a LOWER BOUND of the memory instructions that slot has
+// issued (18 / 16 -> 15, what the 4-bit field takes; 2; else 0) -- the chunk has landed, the slot's traffic may stay in flight for
+// a second phase (an HBM write acknowledge under a chip-wide 3 TB/s of epilogue traffic is not back within one 1.3 us phase).
+// dy = 0 phases carry no slot: there the 5 input pieces of the next K-step are the youngest and vmcnt(5) at dy = 1 is as before.
+//
+// Upstream call sites replaced: conv1 / conv2 tasks of scripts/tilevae.py:115-136 with the custom_group_norm + SiLU in front of
+// the NEXT conv (:218-245, :102-104) and the queue's add_res (:612-616) -- the same set as vae_conv_rec.hip.
+#include "common.h"
+
+using namespace mdt;
+
+#include "conv_rec_common.h"
+
+namespace {
+
+struct DItem {
+    int b, cb, y0, x0;      // cb: 64-cout block
+};
+
+constexpr int D_MT = 2;                  // 32-cout tiles of an item (and of a wave)
+constexpr int D_NROW = 2;                // pixel rows of a wave
+constexpr int D_TH = 16, D_ROWS = D_TH + 2, D_COLS = 34;
+constexpr int ECD = 16;                  // float4 stride between [bias | a | s] of a constants buffer (64 couts x 4 B = 256 B each)
+constexpr int ECD_REC = 3 * ECD;         // records of one constants buffer
+
+constexpr int D_TK = 4;                  // K-steps of one unrolled trip
+// slot of phase p (0 .. 11) of an item's first trip: position i = 2 k + dy - 1 of the dy = 1 / 2 phases, 8 slots
+__host__ __device__ constexpr int slot_pos(int p) { return p % 3 == 0 ? -1 : 2 * (p / 3) + p % 3 - 1; }
+__host__ __device__ constexpr int slot_kind(int p) { return slot_pos(p) < 0 ? 0 : 1 + slot_pos(p) % 2; }   // 0 none, 1: A + R0, 2: R1 + E
+__host__ __device__ constexpr int slot_unit(int p) { return slot_pos(p) / 2; }
+
+#define MDT_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | (n))      // s_waitcnt vmcnt(n), n <= 15 (expcnt / lgkmcnt untouched)
+
+__global__ __launch_bounds__(512, 2) void k_conv3x3_recd(const ConvRParams P) {
+    using IS = InStage<D_ROWS>;
+    constexpr int W_REC = 2 * 3 * D_MT * 64;          // records of a chunk in LDS  [hl][dx][mt][lane]
+    constexpr int W_SRC = 2 * 3 * 4 * 64;             // records of the packed chunk in HBM  [hl][dx][mt 4][lane] (128-cout blocks)
+    constexpr int W_DMA = W_REC / 64;                 // 12 pieces: waves 0-7 take piece w, waves 0-3 also piece w + 8
+    static_assert(IS::DMA % 8 == 0 && IS::PW == 5 && W_DMA == 12, "the counted wait assumes 5 input pieces per wave");
+    __shared__ u32x4 smem[2 * IS::PAD + 3 * W_REC + 2 * ECD_REC];
+    u32x4* const in_l = smem;
+    u32x4* const w_l = smem + 2 * IS::PAD;
+    u32x4* const ec_l = smem + 2 * IS::PAD + 3 * W_REC;
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kg = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Hp = P.H + 2, Wp = rec_pitch(P.W), Pn = P.Cin >> 3, PnO = P.Cout >> 3;
+    const size_t plane = (size_t)Hp * Wp;
+    const int NCB2 = P.Cout >> 6;
+    const int dbg = pdbg(P.dbg);
+
+    // work -> (sample, pixel tile, 64-cout block): as in k_conv3x3_rec (`work % 8` is this block's XCD for all its items: every cout
+    // block of a pixel tile stays on one L2)
+    const int per_img = ((P.ptiles + 7) / 8) * 8 * NCB2, total = per_img * P.B;
+    auto decode = [&](int work, DItem& it) -> bool {
+        it.b = work / per_img;
+        const int r = work - it.b * per_img, xcd = r & 7, slot = r >> 3;
+        const int ptile = (slot / NCB2) * 8 + xcd;
+        it.cb = slot % NCB2;
+        const int py = ptile / P.PX, px = ptile - py * P.PX;
+        it.y0 = py * D_TH;
+        it.x0 = px * 32;
+        return ptile < P.ptiles;
+    };
+    auto next_valid = [&](int work, DItem& it) -> int {
+        while (work < total && !decode(work, it)) work += gridDim.x;
+        return work;
+    };
+
+    auto make_ioff = [&](const DItem& it, unsigned (&ioff)[IS::PW]) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+#pragma unroll
+        for (int i = 0; i < IS::PW; ++i) {
+            const int di = wave + 8 * i;
+            int s = (di % IS::HALF_DMA) * 64 + ln;
+            if (s >= IS::HALF) s = IS::HALF - 1;
+            const int g = s / (D_ROWS * D_COLS), p = s - g * (D_ROWS * D_COLS);
+            const int r = p / D_COLS, c = p - r * D_COLS;
+            int pr = it.y0 + r, pc = it.x0 + c;
+            pr = pr < Hp ? pr : Hp - 1;
+            pc = (pc < P.W + 1 ? pc : P.W + 1) + REC_COL0;
+            ioff[i] = (unsigned)(((size_t)g * plane + (size_t)pr * Wp + pc) * 16);
+        }
+    };
+    auto issue_input = [&](const DItem& it, const unsigned (&ioff)[IS::PW], int k, int stage) {
+        const char* xb = reinterpret_cast<const char*>(P.x + (size_t)it.b * 2 * Pn * plane);
+#pragma unroll
+        for (int i = 0; i < IS::PW; ++i) {
+            const int di = wave + 8 * i;
+            const char* base = xb + ((size_t)(di / IS::HALF_DMA) * Pn + 2 * (size_t)k) * plane * 16;   // wave-uniform
+            dma16(base, ioff[i], in_l + stage * IS::PAD + di * 64);
+        }
+    };
+    const unsigned lane16 = lane * 16;
+    // chunk (k, dy) of the item's 64 couts: piece p = (hl, dx, mt) -> packed piece (hl, dx, 2 (cb & 1) + mt) of the 128-cout block cb >> 1
+    auto issue_weights = [&](const DItem& it, int ph, int ring) {
+        const char* wsrc = reinterpret_cast<const char*>(P.w + ((size_t)(it.cb >> 1) * P.NK * 3 + ph) * W_SRC);
+        const int half2 = (it.cb & 1) * 2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int p = wave + 8 * i;
+            if (p < W_DMA) {
+                const int q = p >> 1, mt = p & 1;      // q = hl * 3 + dx
+                dma16(wsrc + (size_t)((q * 4 + half2 + mt) * 64) * 16, lane16, w_l + ring * W_REC + p * 64);
+            }
+        }
+    };
+    // epilogue constants of an item's 64 couts: waves 0 / 1 / 2 fetch bias / a / s, 256 B each (lanes 0-15)
+    auto issue_consts = [&](const DItem& it, int par) {
+        if (lane < 16) {
+            if (wave == 0 && P.bias) dma16(reinterpret_cast<const char*>(P.bias + it.cb * 64), lane16, ec_l + par * ECD_REC);
+            if ((wave == 1 || wave == 2) && P.yrec && P.coef)
+                dma16(reinterpret_cast<const char*>(P.coef + ((size_t)it.b * 2 + (wave - 1)) * P.Cout + it.cb * 64), lane16,
+                      ec_l + par * ECD_REC + wave * ECD);
+        }
+    };
+
+    bf16x8 fw[2][D_MT][2];     // [set][m][hl]
+    bf16x8 fx[2][D_NROW][2];   // [set][row][hl]
+    const int wfrag = lane;                                          // + ((hl*3 + dx)*2 + m)*64
+    const int xfrag = (kg * D_ROWS + wave * D_NROW) * D_COLS + l31;  // + hl*HALF_PAD + (n + dy)*COLS + dx
+    auto load_fw = [&](int set, int ring, int dx) {
+        const u32x4* wst = w_l + ring * W_REC + wfrag;
+#pragma unroll
+        for (int m = 0; m < D_MT; ++m)
+#pragma unroll
+            for (int hl = 0; hl < 2; ++hl) fw[set][m][hl] = __builtin_bit_cast(bf16x8, wst[((hl * 3 + dx) * D_MT + m) * 64]);
+    };
+    auto load_fx = [&](int set, int stage, int dy, int dx) {
+        const u32x4* ist = in_l + stage * IS::PAD + xfrag + dy * D_COLS + dx;
+#pragma unroll
+        for (int n = 0; n < D_NROW; ++n)
+#pragma unroll
+            for (int hl = 0; hl < 2; ++hl) fx[set][n][hl] = __builtin_bit_cast(bf16x8, ist[hl * IS::HALF_PAD + n * D_COLS]);
+    };
+
+    // ------------------------------------------------------------------------------------------------------------------
+    // the epilogue of unit u = (m-tile, row) of a finished item, in the pieces the slots issue (addressing as epilogue_item:
+    // wave-uniform 64-bit base in SGPRs + 32-bit lane offset; constants read from LDS where they are used)
+    const size_t HW = (size_t)P.H * P.W, HW4 = HW * sizeof(float);
+    const size_t pl16 = plane * sizeof(u32x4), lo_half = (size_t)PnO * pl16;
+    const bool has_act = P.yrec != nullptr && P.coef != nullptr;
+    struct Lane {
+        int x, y;
+        bool ok;
+        unsigned kgo, xc;
+    };
+    auto lane_of = [&](const DItem& it, int n) {
+        Lane L;
+        unsigned kgo = (unsigned)kg;
+        asm volatile("" : "+v"(kgo));      // formed per slot: as loop invariants these offsets end up in scratch
+        int le = lane;
+        asm volatile("" : "+v"(le));
+        L.kgo = kgo;
+        L.x = it.x0 + (le & 31);
+        L.y = it.y0 + wave * D_NROW + n;
+        L.ok = L.x < P.W && L.y < P.H;
+        L.xc = (unsigned)(L.x < P.W ? L.x : 0);
+        return L;
+    };
+    // A: + bias, fp32 stores
+    auto slot_a = [&](f32x16 (&S)[D_MT][D_NROW][1], const DItem& it, const u32x4* ec, int m, int n) {
+        const Lane L = lane_of(it, n);
+        if (P.bias) {
+            const float4* e4 = reinterpret_cast<const float4*>(ec) + (m * 8 + L.kgo);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 tb = e4[2 * g];
+                S[m][n][0][4 * g] += tb.x; S[m][n][0][4 * g + 1] += tb.y; S[m][n][0][4 * g + 2] += tb.z; S[m][n][0][4 * g + 3] += tb.w;
+            }
+        }
+        if (P.y32 && L.ok) {
+            const unsigned ro = ((4u * L.kgo) * (unsigned)HW + L.xc) * 4u + (unsigned)(L.y * P.W) * 4u;
+            char* const yb32 = reinterpret_cast<char*>(P.y32) + ((size_t)it.b * P.Cout + (size_t)(it.cb * D_MT + m) * 32) * HW4;
+            gchar* up = uniform_ptr(yb32);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                if (q) up = uniform_ptr(up + MDT_PLANE_STEP(q) * HW4);
+                *(MDT_GLOBAL float*)(up + (size_t)ro) = S[m][n][0][q];
+            }
+        }
+    };
+    // R: activation + split + record stores of 8 of the lane's 16 channels (R = 0 / 1)
+    auto slot_r = [&](f32x16 (&S)[D_MT][D_NROW][1], const DItem& it, const u32x4* ec, int m, int n, int R) {
+        if (!P.yrec) return;
+        const Lane L = lane_of(it, n);
+        if (!L.ok) return;
+        const float4* e4 = reinterpret_cast<const float4*>(ec) + (m * 8 + L.kgo);
+        char* const yr = reinterpret_cast<char*>(P.yrec) + ((size_t)it.b * 2 * PnO + (size_t)(it.cb * D_MT + m) * 4) * pl16;
+        const unsigned rrow = (L.kgo * (unsigned)plane + (L.xc + (unsigned)REC_COL0)) * 16u + (unsigned)((L.y + 1) * Wp) * 16u;
+        {
+        if (has_act) {
+            f32x2 aq[4], sq[4];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const float4 ta = e4[ECD + 4 * R + 2 * g], ts = e4[2 * ECD + 4 * R + 2 * g];
+                aq[2 * g] = f32x2{ta.x, ta.y}; aq[2 * g + 1] = f32x2{ta.z, ta.w};
+                sq[2 * g] = f32x2{ts.x, ts.y}; sq[2 * g + 1] = f32x2{ts.z, ts.w};
+            }
+            act8(S[m][n][0], 8 * R, aq, sq);
+        }
+        gchar* const yp = uniform_ptr(yr + (size_t)(2 * R) * pl16), *const ypl = uniform_ptr(yp + lo_half);
+        u32x4 hi, lo;
+        split8p(S[m][n][0], 8 * R, hi, lo);
+        const size_t at = (size_t)(rrow + 16u);
+        *(MDT_GLOBAL u32x4*)(yp + at) = hi;
+        *(MDT_GLOBAL u32x4*)(ypl + at) = lo;
+        }
+    };
+    // zero border of the record image: this block owns the border cells next to its edge pixels.  Coordinates only, no accumulator data:
+    // ONE rolled loop per item over the wave's 2 rows x 2 m-tiles x 2 record pairs (edge tiles only; issued with the item's last R slot)
+    auto zero_border = [&](const DItem& it) {
+        if (!P.yrec) return;
+        const Lane L0 = lane_of(it, 0);
+        if (!(L0.x < P.W)) return;
+        const bool left = L0.x == 0, right = L0.x + 1 == P.W;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        const unsigned p0 = (L0.kgo * (unsigned)plane + (unsigned)REC_COL0) * 16u;
+#pragma unroll 1
+        for (int j = 0; j < 2 * D_NROW * D_MT; ++j) {
+            const int n = j & 1, RR = (j >> 1) & 1, m = j >> 2;
+            const int y = L0.y + n;
+            if (y >= P.H) continue;
+            const bool top = y == 0, bot = y == P.H - 1;
+            if (!(left || right || top || bot)) continue;
+            char* const ypz = reinterpret_cast<char*>(P.yrec) + ((size_t)it.b * 2 * PnO + (size_t)(it.cb * D_MT + m) * 4 + 2 * RR) * pl16;
+            auto zrec = [&](int py, int px) {      // (px: padded column, 0 = left border)
+                const size_t az = (size_t)(p0 + (unsigned)(py * Wp + px) * 16u);
+                *reinterpret_cast<u32x4*>(ypz + az) = z;
+                *reinterpret_cast<u32x4*>(ypz + lo_half + az) = z;
+            };
+            if (left) zrec(y + 1, 0);
+            if (right) zrec(y + 1, P.W + 1);
+            if (top) {
+                zrec(0, L0.x + 1);
+                if (left) zrec(0, 0);
+                if (right) zrec(0, P.W + 1);
+            }
+            if (bot) {
+                zrec(P.H + 1, L0.x + 1);
+                if (left) zrec(P.H + 1, 0);
+                if (right) zrec(P.H + 1, P.W + 1);
+            }
+        }
+    };
+    // E: the unit's registers are stored -- the residual row of item `it` (the block's NEXT item) goes into them, or zeros
+    auto res_rows = [&](const DItem& it) {
+        ResRows<D_NROW> R;
+        R.on = true; R.b = it.b; R.mt_global0 = it.cb * D_MT;
+#pragma unroll
+        for (int n = 0; n < D_NROW; ++n) R.ys[n] = it.y0 + wave * D_NROW + n;
+        int le = lane;
+        asm volatile("" : "+v"(le));
+        R.x = it.x0 + (le & 31);
+        R.x_ok = R.x < P.W;
+        return R;
+    };
+    auto slot_e = [&](f32x16 (&S)[D_MT][D_NROW][1], const DItem& it, bool on, int m, int n) {
+        if (P.res != nullptr && !(dbg & 1)) {
+            if (!on) return;
+            const ResRows<D_NROW> R = res_rows(it);
+            if (n == 0) residual_into_acc<D_NROW, D_MT, 1>(P.res, P.Cout, HW, P.H, P.W, kg, R, m, 0, S);
+            else residual_into_acc<D_NROW, D_MT, 1>(P.res, P.Cout, HW, P.H, P.W, kg, R, m, 1, S);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) S[m][n][0][q] = 0.0f;
+        }
+    };
+
+    // ------------------------------------------------------------------------------------------------------------------
+    DItem cur, nxt, prv;
+    int work = next_valid(blockIdx.x, cur);
+    if (work >= total) return;
+    prv = cur;
+    unsigned ioff[IS::PW];
+    make_ioff(cur, ioff);
+    issue_input(cur, ioff, 0, 0);
+    issue_weights(cur, 0, 0);
+    issue_weights(cur, 1, 1);
+    issue_consts(cur, 0);
+    const int nph = P.NK * 3;
+    int par = 0;                 // constants buffer of `cur`; the sealed item's is par ^ 1
+    bool have_prev = false;
+
+    f32x16 acc[D_MT][D_NROW][1], sealed[D_MT][D_NROW][1];
+    // the first item's start values go into `sealed` and change sides at the loop top like every later item's
+#pragma unroll
+    for (int m = 0; m < D_MT; ++m)
+#pragma unroll
+        for (int n = 0; n < D_NROW; ++n) {
+            slot_e(sealed, cur, true, m, n);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[m][n][0][q] = 0.0f;
+        }
+
+    while (true) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces of the item's first operands have landed, its residual rows, and every store of the slots is out
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // the sets change roles: acc <- start values of `cur` (residual or zeros), sealed <- the sums of `prv`
+#pragma unroll
+        for (int m = 0; m < D_MT; ++m)
+#pragma unroll
+            for (int n = 0; n < D_NROW; ++n) {
+                const f32x16 t = acc[m][n][0];
+                acc[m][n][0] = sealed[m][n][0];
+                sealed[m][n][0] = t;
+            }
+        load_fw(0, 0, 0);
+        load_fx(0, 0, 0, 0);
+        const int work_n = next_valid(work + gridDim.x, nxt);
+        const bool has_next = work_n < total;
+        unsigned ioff_n[IS::PW];
+        if (has_next) make_ioff(nxt, ioff_n);
+        const u32x4* const ec_prev = ec_l + (par ^ 1) * ECD_REC;
+        const bool drip = have_prev && !(dbg & 1);
+
+        for (int k8 = 0; k8 < P.NK; k8 += D_TK) {
+            const bool first = k8 == 0;
+#pragma unroll
+            for (int t = 0; t < 9 * D_TK; ++t) {
+                const int kk = t / 9, dy = (t / 3) % 3, dx = t % 3, pl_ = t / 3;      // pl_: phase of the trip, 0 .. 11
+                const int k = k8 + kk, ph = k * 3 + dy;
+                const int ws = t & 1;
+                // ---- the NEXT step's fragments go out first
+                MDT_PIN();
+                if (t < 9 * D_TK - 1) {
+                    const int t1 = t + 1;
+                    load_fw(ws ^ 1, (t1 / 3) % 3, t1 % 3);
+                    load_fx(ws ^ 1, (t1 / 9) & 1, (t1 / 3) % 3, t1 % 3);
+                } else if (k8 + D_TK < P.NK) {
+                    load_fw(ws ^ 1, 0, 0);
+                    load_fx(ws ^ 1, 0, 0, 0);
+                }
+                MDT_PIN();
+                // ---- this step's MFMAs: term-major over the wave's four accumulators
+#pragma unroll
+                for (int term = 0; term < 3; ++term)
+#pragma unroll
+                    for (int n = 0; n < D_NROW; ++n)
+#pragma unroll
+                        for (int m = 0; m < D_MT; ++m)
+                            acc[m][n][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ws][m][term == 0 ? 1 : 0], fx[ws][n][term == 1 ? 1 : 0],
+                                                                                   acc[m][n][0], 0, 0, 0);   // w_lo x_hi, w_hi x_lo, w_hi x_hi
+                MDT_PIN();
+                if (dx == 0) {
+                    // in flight, oldest first: [the slot traffic of phase ph-2] chunk ph+1 (requested behind the previous barrier), then
+                    // EITHER the slot traffic of phase ph-1 (N memory instructions, see the file header) OR -- at dy = 1 -- the 5 input
+                    // pieces of K-step k+1: those youngest ones may stay in flight one more phase, everything older has to be in
+                    constexpr int PL = 3 * D_TK;
+                    const int pp = (pl_ + PL - 1) % PL;                          // the phase before this one (phase 0: the last one of the trip before)
+                    const int pk = slot_kind(pp);
+                    const bool pfirst = pl_ > 0 ? first : k8 == D_TK;            // ... and whether it carried its slot (first trip only)
+                    bool counted = false;
+                    if (pk != 0 && pfirst) {
+                        const bool yok = drip && prv.y0 + wave * D_NROW + (slot_unit(pp) & 1) < P.H;      // wave-uniform: did the slot issue its stores
+                        const bool big = pk == 1 ? (yok && P.y32 != nullptr) : (P.res != nullptr && has_next && !(dbg & 1));      // >= 16 of them
+                        if (big) { MDT_VMCNT(15); counted = true; }
+                        else if (yok && P.yrec != nullptr) { MDT_VMCNT(2); counted = true; }
+                    }
+                    if (!counted) {
+                        if (dy == 1 && k + 1 < P.NK) MDT_VMCNT(5);
+                        else MDT_VMCNT(0);
+                    }
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                }
+                // requests of this phase, staggered between the two waves that share a SIMD (w and w + 4): waves 0-3 right behind the
+                // barrier, waves 4-7 one step later.  Order inside a phase: chunk ph+2, then EITHER the slot (previous item's results
+                // out / next item's residual in; dy = 1, 2) OR the input stage of K-step k+1 (dy = 0) -- the youngest requests.
+                if ((dx == 0 && wave < 4) || (dx == 1 && wave >= 4)) {
+                    if (ph + 2 < nph) issue_weights(cur, ph + 2, (dy + 2) % 3);
+                    const int sk = slot_kind(pl_), su = sk ? slot_unit(pl_) : 0, sm = su >> 1, sn = su & 1;
+                    if (sk != 0 && first) {
+                        if (sk == 1) {
+                            if (drip) {
+                                slot_a(sealed, prv, ec_prev, sm, sn);
+                                slot_r(sealed, prv, ec_prev, sm, sn, 0);
+                            }
+                        } else {
+                            if (drip) {
+                                slot_r(sealed, prv, ec_prev, sm, sn, 1);
+                                if (su == 3) zero_border(prv);
+                            }
+                            slot_e(sealed, nxt, has_next, sm, sn);
+                        }
+                    }
+                    if (dy == 0 && k + 1 < P.NK) issue_input(cur, ioff, k + 1, (kk + 1) & 1);
+                    if (kk == D_TK - 1 && dy == 2 && k + 1 == P.NK && has_next) {
+                        // last phase of the item: ring slots 0 / 1 and input stage 0 are out of use -> the next item's first operands
+                        issue_input(nxt, ioff_n, 0, 0);
+                        issue_weights(nxt, 0, 0);
+                        issue_weights(nxt, 1, 1);
+                        issue_consts(nxt, par ^ 1);
+                    }
+                }
+            }
+        }
+
+        prv = cur;
+        have_prev = true;
+        if (!has_next) break;
+        work = work_n;
+        cur = nxt;
+        par ^= 1;
+#pragma unroll
+        for (int i = 0; i < IS::PW; ++i) ioff[i] = ioff_n[i];
+    }
+
+    // the block's last item: nothing left to hide under -- its epilogue in one piece
+    if (!(dbg & 1)) {
+        const u32x4* const ec_last = ec_l + par * ECD_REC;
+#pragma unroll
+        for (int m = 0; m < D_MT; ++m)
+#pragma unroll
+            for (int n = 0; n < D_NROW; ++n) {
+                slot_a(acc, prv, ec_last, m, n);
+                slot_r(acc, prv, ec_last, m, n, 0);
+                slot_r(acc, prv, ec_last, m, n, 1);
+            }
+        zero_border(prv);
+    }
+}
+
+}  // namespace
+
+namespace mdt {
+
+// cin % 64 == 0 (whole 4-K-step trips), 128-cout packed blocks; H, W: output = input size
+bool conv_recd_supported(int cout, int cin) { return cin % 64 == 0 && cin >= 128 && cout % 128 == 0; }
+
+int conv_recd_launch(ConvRParams P, int B, hipStream_t s, int cus) {
+    P.PX = (P.W + 31) / 32;
+    P.ptiles = P.PX * ((P.H + 15) / 16);
+    const long long items = (long long)((P.ptiles + 7) / 8) * 8 * (P.Cout / 64) * B;
+    const int grid_max = cus / 8 * 8;
+    dim3 grid((unsigned)(items < grid_max ? items : grid_max)), block(512);
+    hipLaunchKernelGGL(k_conv3x3_recd, grid, block, 0, s, P);
+    MDT_LAUNCH_CHECK();
+    return MDTILE_OK;
+}
+
+}  // namespace mdt

@@ -23,6 +23,8 @@ METHOD_MD, METHOD_MOD = 0, 1
 REGION_BG, REGION_FG = 0, 1
 BLEND_PARTIAL, BLEND_TILE_RANGE, BLEND_PACKED = 1, 2, 4
 CONV_UPSAMPLE2X = 1
+CONV_REC_DRIP = 16
+CONV_REC_ONE_BLOCK, CONV_REC_TWO_BLOCKS = 4, 8      # call_rec(family=...): name the record-conv kernel family (tests / probes); 0 = per launch
 CONV_EXACT_F32 = 2
 ATTN_EXACT_F32 = 1
 ATTN_V_CHANNEL_MAJOR = 2
@@ -126,7 +128,7 @@ _SIGNATURES = {
     "mdtile_conv2d_rec": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                   c_int, c_int, c_void_p]),
     "mdtile_upconv2d_rec_window": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_int, c_int,
-                                                                                                                  c_void_p]),
+                                                                                                                  c_int, c_void_p]),
     "mdtile_vae_attn_ws_size": (c_size_t, [c_int, c_int, c_int]),
     "mdtile_vae_attn_takes_channel_major": (c_int, [c_int, c_int]),
     "mdtile_vae_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p]),
@@ -762,7 +764,8 @@ class PackedConv:
         return bool(lib().mdtile_conv2d_rec_supported(self.cout, self.cin, self.ksize, CONV_UPSAMPLE2X if upsample2x else 0))
 
     def call_rec(self, x: RecImage, residual: Optional[torch.Tensor] = None, upsample2x: bool = False, want_f32: bool = True,
-                 want_rec: bool = False, rec_coef: Optional[torch.Tensor] = None, window: Optional[Tuple[int, int, int, int]] = None):
+                 want_rec: bool = False, rec_coef: Optional[torch.Tensor] = None, window: Optional[Tuple[int, int, int, int]] = None,
+                 family: int = 0):
         """y = conv(x_rec) + bias (+ residual) -> (fp32 NCHW or None, RecImage or None).  The record output is
         split(silu(a y + s)) with rec_coef = gn_coeffs(...) of the NEXT norm, or split(y) when rec_coef is None.
         window = (y0, x0, h, w) in INPUT pixels (upsample2x only; y0, x0: ints, or one int per image): the conv of that window of x,
@@ -782,7 +785,7 @@ class PackedConv:
                 _dev_tensor(rec_coef, "rec_coef", torch.float32)
                 assert want_rec and tuple(rec_coef.shape) == (B, 2, self.cout)
             _check(lib().mdtile_upconv2d_rec_window(_p(x.data), _p(self.packed), _p(self.bias_rec), _p(y), None if yr is None else _p(yr.data),
-                                                    _p(rec_coef), B, self.cin, self.cout, H, W, (c_int * B)(*y0), (c_int * B)(*x0), h, w, _stream()),
+                                                    _p(rec_coef), B, self.cin, self.cout, H, W, (c_int * B)(*y0), (c_int * B)(*x0), h, w, int(family), _stream()),
                    "mdtile_upconv2d_rec_window")
             return y, yr
         if upsample2x:
@@ -796,7 +799,7 @@ class PackedConv:
             _dev_tensor(rec_coef, "rec_coef", torch.float32)
             assert want_rec and tuple(rec_coef.shape) == (B, 2, self.cout)
         _check(lib().mdtile_conv2d_rec(_p(x.data), _p(self.packed), _p(self.bias_rec), _p(residual), _p(y), None if yr is None else _p(yr.data),
-                                       _p(rec_coef), B, self.cin, self.cout, H, W, CONV_UPSAMPLE2X if upsample2x else 0, _stream()),
+                                       _p(rec_coef), B, self.cin, self.cout, H, W, (CONV_UPSAMPLE2X if upsample2x else 0) | int(family), _stream()),
                "mdtile_conv2d_rec")
         return y, yr
 

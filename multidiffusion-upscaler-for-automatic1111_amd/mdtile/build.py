@@ -25,8 +25,11 @@ STAMP = os.path.join(HERE, ".libmdtile.stamp")
 # -pragma-unroll-threshold: the record conv kernels (csrc/vae_conv_rec.hip) keep two fragment register sets whose indices are
 # compile-time only after their 36- / 24-step K-loop bodies are FULLY unrolled; the default budget (16 K instructions, estimated
 # before constant folding) is too small for that and a partial unroll would turn the register arrays into scratch memory.
+# -DMDTILE_PROBES=0: the shipping library carries no probe scaffolding (csrc/common.h: kProbes / probe_env); build_probes() below
+# makes the instrumented twin the scripts under probes/ load.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-               "-Wall", "-Wno-unused-function", "-mllvm", "-pragma-unroll-threshold=262144"]
+               "-Wall", "-Wno-unused-function", "-mllvm", "-pragma-unroll-threshold=262144", "-DMDTILE_PROBES=0"]
+PROBES_LIB = os.path.join(os.path.dirname(EXT_ROOT), "probes", "_ab", "libmdtile_probes.so")
 
 
 def _sources():
@@ -94,5 +97,37 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+def build_probes(verbose: bool = True) -> str:
+    """The PROBES twin of the library (-DMDTILE_PROBES=1: MDTILE_REC_DBG / _STAMPS / _GRID / _BLOCKS / _PERSIST / _STAGGER_PCT,
+    MDTILE_REC2_*, MDTILE_BLEND_CFG, MDTILE_ATTN_SPLIT, MDTILE_C1X1_STREAM are read per launch) -> probes/_ab/libmdtile_probes.so
+    (git-ignored, travels with gpurun).  probes/_probes_lib.py: use(E) points the ctypes binding at it before the first call; never shipped, never the default."""
+    hipcc = hipcc_path()
+    if hipcc is None:
+        raise RuntimeError("hipcc not found")
+    os.makedirs(os.path.dirname(PROBES_LIB), exist_ok=True)
+    flags = [f for f in HIPCC_FLAGS if f != "-DMDTILE_PROBES=0"] + ["-DMDTILE_PROBES=1"]
+    objdir = os.path.join(EXT_ROOT, "build", "probes")
+    os.makedirs(objdir, exist_ok=True)
+    procs, objs = [], []
+    for src in _sources():
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        procs.append((src, subprocess.Popen([hipcc] + [f for f in flags if f != "-shared"] + ["-c", src, "-o", obj],
+                                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", PROBES_LIB] + objs, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}")
+    if verbose:
+        print(f"[mdtile] built {PROBES_LIB} (probes twin)")
+    return PROBES_LIB
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--probes" in sys.argv:
+        build_probes()
+    else:
+        build(force="--force" in sys.argv)

@@ -330,7 +330,7 @@ class VAEHook:
                     st.x = s.conv.down2(st.x)
                 elif self._pooled_site_takes_rec(s):
                     # pooled-statistics site on the record kernels: one conversion pass (norm + SiLU fused into it) + the record conv --
-                    # bit for bit the fp32 hand-over kernel's output, cheaper where _pooled_site_takes_rec says so
+                    # the fp32 hand-over kernel's output to fp32 rounding (a fused residual enters the accumulation first here: (res + sum) + bias), cheaper where _pooled_site_takes_rec says so
                     xrec = self.engine.rec_from_f32(st.x, st.pre)
                     st.x, _ = s.conv.call_rec(xrec, residual=st.res.pop() if s.fuse_res else None, upsample2x=s.upsample, want_f32=True, want_rec=False)
                 else:
@@ -531,23 +531,29 @@ class VAEHook:
             return None
         return frozen
 
-    def _pooled_across_ranks(self, gp: "GroupNormParam", steps, dev):
+    def _pooled_across_ranks(self, gp: "GroupNormParam", steps, dev, interrupted: bool = False):
         """Slow mode on several GPUs: all-reduce(sum) of [sum px*mean, sum px*var, sum px] (2*B*32+1 floats) per barrier, on the
-        job's data plane (the engine's RCCL communicator when the process has one, mdtile/sharding.py)."""
+        job's data plane (the engine's RCCL communicator when the process has one, mdtile/sharding.py).
+        Returns (pooled or None, any rank interrupted).  The interrupt rides in the `head` exchange every rank enters at every pooled
+        barrier: a rank that saw state.interrupted keeps walking the barriers (with no tiles) until it has said so HERE, and all ranks
+        leave the lockstep loop together -- a rank that simply left would pair its next collective (the 2-float agreement in front of
+        the gather) with its peers' `head` and hang them in allreduce_stats."""
         from mdtile import sharding
         BG = None
-        if gp.var_list:
+        if gp.var_list and not interrupted:
             px = torch.tensor(gp.pixel_list, dtype=torch.float32, device=dev).unsqueeze(1)
             sm, sv, sp = (torch.vstack(gp.mean_list) * px).sum(0), (torch.vstack(gp.var_list) * px).sum(0), px.sum().view(1)
             BG = sm.numel()
         # who still has tiles at this barrier, and how wide the statistics rows are (ranks without tiles contribute zeros)
-        head = sharding.comm_allreduce_sum(torch.tensor([1.0 if BG else 0.0, float(BG or 0)], dtype=torch.float64, device=dev))
+        head = sharding.comm_allreduce_sum(torch.tensor([1.0 if BG else 0.0, float(BG or 0), 1.0 if interrupted else 0.0], dtype=torch.float64, device=dev))
+        if head[2].item() > 0.0:
+            return None, True
         if head[0].item() == 0.0:
-            return None
+            return None, False
         if BG is None:
             BG = int(round(head[1].item() / head[0].item()))
             sm, sv, sp = torch.zeros(BG, device=dev), torch.zeros(BG, device=dev), torch.zeros(1, device=dev)
-        return sharding.allreduce_stats(sm, sv, sp)
+        return sharding.allreduce_stats(sm, sv, sp), False
 
     # ---- single-process multi-device sweep ---------------------------------------------------------------------------------
     def _program_on(self, index: int) -> List[Step]:
@@ -698,9 +704,10 @@ class VAEHook:
                     return rep_cache[T]
 
                 def regather(chunk):                 # inputs that were folded into a stacked copy: cut them out of z again
-                    for i in chunk:
-                        b = in_bboxes[i]
-                        tiles[i].x = E.gather_rect(z, b[0], b[2], b[1] - b[0], b[3] - b[2])
+                    for i in chunk:                  # (tiles of the chunk that already FINISHED -- an OOM inside finish() -- are None: left alone)
+                        if tiles[i] is not None:
+                            b = in_bboxes[i]
+                            tiles[i].x = E.gather_rect(z, b[0], b[2], b[1] - b[0], b[3] - b[2])
 
                 def run_stack(chunk):
                     T = len(chunk)
@@ -717,19 +724,22 @@ class VAEHook:
                         tiles[i].x = yb[t * N:(t + 1) * N]
                         finish(i)
 
-                def sweep(groups, run_chunk, restore, origins: bool):
+                def sweep(groups, run_chunk, restore):
                     nonlocal interrupted
                     for key in sorted(groups, key=lambda kk: -len(groups[kk])):
                         ids = groups[key]
                         tb = self._tile_batch_that_fits(N, key[:2], dev)
-                        if origins and tb * N > 8:
-                            tb = max(1, 8 // N)        # mdtile_upconv2d_rec_window keeps 8 window origins per launch
+                        if len(key) > 2 and tb * N > 8:       # the group carries narrowed windows (key = shape + window entries):
+                            tb = max(1, 8 // N)               # mdtile_upconv2d_rec_window keeps 8 window origins per launch
                         c0 = 0
                         while c0 < len(ids):
                             if state.interrupted:
                                 interrupted = True
                                 return
-                            chunk = ids[c0:c0 + tb]
+                            chunk = [i for i in ids[c0:c0 + tb] if tiles[i] is not None]      # (after an OOM retry: not the tiles that finished)
+                            if not chunk:
+                                c0 += tb
+                                continue
                             try:
                                 run_chunk(chunk)
                             except torch.cuda.OutOfMemoryError:
@@ -740,12 +750,12 @@ class VAEHook:
                                 restore(chunk)
                                 tb = 1
                                 continue
-                            c0 += len(chunk)
+                            c0 += tb
 
                 groups: Dict[tuple, List[int]] = {}
                 for i in mine:
                     groups.setdefault(tuple(tiles[i].x.shape[2:]) + tuple((k, w[2], w[3]) for k, w in sorted(live[i][0].items())), []).append(i)
-                sweep(groups, run_stack, regather, True)
+                sweep(groups, run_stack, regather)
                 mine = []        # all done (or interrupted)
             for i in mine:
                 if state.interrupted:
@@ -768,26 +778,34 @@ class VAEHook:
             # (semi-fast: the first len(frozen) norms use the frozen statistics instead of the pool)
             forward = True
             k_norm = 0
-            while not interrupted:
+            while True:
                 use_frozen = frozen is not None and k_norm < len(frozen)
                 gp = GroupNormParam(E)
-                for i in (mine if forward else reversed(mine)):
+                for i in (() if interrupted else mine if forward else reversed(mine)):
                     if state.interrupted:
                         interrupted = True
                         break
                     self._run_until_norm(steps, tiles[i])
                     if tiles[i].pc < len(steps) and not use_frozen:
                         gp.add_tile(tiles[i].x)
-                if interrupted:
+                if interrupted and world == 1:
                     break
+                # several ranks: an interrupted rank runs no more tiles but keeps walking the norms to the next POOLED barrier, where the
+                # `head` exchange tells every rank (see _pooled_across_ranks) -- all of them leave this loop at the same barrier
                 if use_frozen:
                     # a frozen norm is no barrier upstream (the tile runs straight through it): no pooling, no collective,
                     # no change of the zig-zag direction.  A later pooled norm always exists in this branch.
-                    for i in mine:
+                    for i in (() if interrupted else mine):
                         self._apply_norm(steps, tiles[i], *frozen[k_norm])
                     k_norm += 1
                     continue
-                pooled = gp.summary() if world == 1 else self._pooled_across_ranks(gp, steps, z.device)
+                if world == 1:
+                    pooled = gp.summary()
+                else:
+                    pooled, any_interrupted = self._pooled_across_ranks(gp, steps, z.device, interrupted)
+                    if any_interrupted:
+                        interrupted = True
+                        break
                 k_norm += 1
                 if pooled is None:
                     for i in mine:

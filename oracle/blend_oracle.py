@@ -6,7 +6,7 @@ The shipped path (multidiffusion-upscaler-for-automatic1111_amd/) never does.
 
 Parity status: PINNED.  The reference ships no golden vectors, so this restatement is
 pinned by (a) tests/test_oracle_vs_reference.py, which runs the upstream Python itself under
-oracle/stub_host.py whenever /root/reference is mounted, and (b) tests/golden/*.npz, which were produced
+hostsim/stub_host.py whenever /root/reference is mounted, and (b) tests/golden/*.npz, which were produced
 by the upstream code (tests/golden/make_golden.py) and travel to the GPU box.
 
 Every function cites the upstream lines it follows.  All arithmetic is fp32 torch-on-CPU (grid ints are

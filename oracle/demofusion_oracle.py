@@ -3,7 +3,7 @@ ORACLE (test infrastructure only) -- CPU restatement of upstream's DemoFusion mo
 (tile_methods/demofusion.py:93-162 window / view construction, :164-178 Gaussian filter, :219-324 sample_one_step).
 
 Only tests/ may import this file.  Parity status: PINNED by tests/test_oracle_vs_reference.py::test_demofusion_* (runs the upstream
-DemoFusion delegate itself under oracle/stub_host.py with the same `random` seed and compares bit for bit).
+DemoFusion delegate itself under hostsim/stub_host.py with the same `random` seed and compares bit for bit).
 """
 from __future__ import annotations
 

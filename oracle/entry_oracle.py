@@ -5,7 +5,7 @@ of `model_wrap_cfg.inner_model.forward(x, sigma, cond=...)` and the blend, i.e. 
 52-129) and the whole-batch branch of the per-region forwards (tile_methods/abstractdiffusion.py:231-287, 429-451).
 
 Only tests/ may import this file.  Parity status: PINNED -- tests/test_md_entry_path.py runs the upstream delegate itself (hook() and
-three sampler steps on a conditioning-dependent stand-in model) under oracle/stub_host.py next to these functions with torch.equal,
+three sampler steps on a conditioning-dependent stand-in model) under hostsim/stub_host.py next to these functions with torch.equal,
 and tests/golden/entry.npz (made by tests/golden/make_golden_entry.py from the upstream code) carries the pin to the GPU box.
 """
 from __future__ import annotations

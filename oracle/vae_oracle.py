@@ -4,7 +4,7 @@ ORACLE (test infrastructure only) -- CPU restatement of the reference's Tiled-VA
 Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may import this file.
 
 Parity status: PINNED by tests/test_oracle_vs_reference.py (runs upstream `VAEHook` itself under
-oracle/stub_host.py when /root/reference is mounted) and by tests/golden/vae_*.npz (produced by the upstream code,
+hostsim/stub_host.py when /root/reference is mounted) and by tests/golden/vae_*.npz (produced by the upstream code,
 see tests/golden/make_golden.py).
 
 The restatement is functional: the decoder is linearised into a flat op list (what upstream calls the task

@@ -4,6 +4,9 @@ configurations (nontemporal tile loads / canvas stores were A/B'd here in round 
 import os, sys, torch
 sys.path.insert(0, "multidiffusion-upscaler-for-automatic1111_amd"); sys.path.insert(0, ".")
 import mdtile as E
+import _probes_lib
+_probes_lib.use(E)      # probe switches exist in the PROBES twin of the library only
+
 dev = torch.device("cuda:0")
 W = H = 1024; tw = th = 128; ov = 8; N, C = 2, 4
 plan = E.Plan(W, H, tw, th, ov, 8)

@@ -2,6 +2,9 @@ import os, sys, torch
 ROOT = "/root/repo" if os.path.exists("/root/repo/probes") else os.getcwd()
 sys.path.insert(0, os.path.join(ROOT, "multidiffusion-upscaler-for-automatic1111_amd")); sys.path.insert(0, ROOT)
 import mdtile as E
+import _probes_lib
+_probes_lib.use(E)      # probe switches exist in the PROBES twin of the library only
+
 dev = torch.device("cuda:0")
 def timeit(fn, n=4, rounds=3):
     best = 1e9

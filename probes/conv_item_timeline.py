@@ -4,6 +4,9 @@ import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "multidiffusion-upscaler-for-automatic1111_amd")); sys.path.insert(0, ROOT)
 import mdtile as E
+import _probes_lib
+_probes_lib.use(E)      # probe switches exist in the PROBES twin of the library only
+
 dev = torch.device("cuda:0")
 os.environ["MDTILE_REC_BLOCKS"] = "1"
 for cin, cout, H, W in ((128, 128, 2224, 2224), (512, 512, 556, 556)):

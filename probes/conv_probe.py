@@ -9,6 +9,9 @@ sys.path.insert(0, os.path.join(ROOT, "multidiffusion-upscaler-for-automatic1111
 sys.path.insert(0, ROOT)
 import mdtile as E
 
+import _probes_lib
+_probes_lib.use(E)      # probe switches exist in the PROBES twin of the library only
+
 dev = torch.device("cuda:0")
 SHAPES = [  # cin, cout, H, W, upsample
     (512, 512, 278, 278, False),

@@ -11,6 +11,9 @@ sys.path.insert(0, os.path.join(ROOT, "multidiffusion-upscaler-for-automatic1111
 sys.path.insert(0, ROOT)
 import mdtile as E
 
+import _probes_lib
+_probes_lib.use(E)      # probe switches exist in the PROBES twin of the library only
+
 dev = torch.device("cuda:0")
 SHAPES = [(512, 512, 556, 556), (512, 512, 278, 278), (256, 256, 1112, 1112), (512, 256, 1112, 1112), (128, 128, 2224, 2224),
           (128, 128, 128, 128, 304), (128, 128, 512, 512, 19)]      # 5, 6: the pixel count of 2224^2 as many small images (planes of 64 KB / 1 MB: few pages per item)

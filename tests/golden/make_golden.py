@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """
 Regenerates the golden fixtures in this directory by running the UPSTREAM reference code itself
-(/root/reference, imported verbatim under oracle/stub_host.py) on CPU, fp32.
+(/root/reference, imported verbatim under hostsim/stub_host.py) on CPU, fp32.
 
     python tests/golden/make_golden.py
 

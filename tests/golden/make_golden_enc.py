@@ -1,5 +1,5 @@
 """Golden vectors for the ENCODER direction of Tiled VAE, produced by the UPSTREAM code (scripts/tilevae.py of the reference
-mounted at /root/reference) under oracle/stub_host.py.  Run here (the reference does not exist on the GPU box):
+mounted at /root/reference) under hostsim/stub_host.py.  Run here (the reference does not exist on the GPU box):
 
     python tests/golden/make_golden_enc.py        ->  tests/golden/vae_enc.npz + tests/golden/cases_enc.json
 """

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Regenerates tests/golden/entry.npz by running the UPSTREAM MultiDiffusion delegate (hook() + three sampler steps through
-`inner_model.forward`, tile_methods/multidiffusion.py:15-29, 52-129) under oracle/stub_host.py -- see tests/entry_driver.py for the
+`inner_model.forward`, tile_methods/multidiffusion.py:15-29, 52-129) under hostsim/stub_host.py -- see tests/entry_driver.py for the
 stand-in model and the cases.      python tests/golden/make_golden_entry.py"""
 import os
 import sys

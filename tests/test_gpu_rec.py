@@ -185,7 +185,7 @@ def test_upconv_window_equals_the_same_pixels_of_the_whole_image_call(plugin, cu
     x = torch.randn(B, cin, Hin, Win).to(cuda)
     coef = _coef(B, cout, 5).to(cuda)
     xr = E.rec_from_f32(x)
-    y_full, r_full = pc.call_rec(xr, upsample2x=True, want_f32=True, want_rec=True, rec_coef=coef)
+    y_full, r_full = pc.call_rec(xr, upsample2x=True, want_f32=True, want_rec=True, rec_coef=coef, family=blocks)
     y0, x0, h, w = win
     y_win, r_win = pc.call_rec(xr, upsample2x=True, want_f32=True, want_rec=True, rec_coef=coef, window=win)
     assert y_win.shape == (B, cout, 2 * h, 2 * w) and r_win.shape == (B, cout, 2 * h, 2 * w)
@@ -318,11 +318,11 @@ def test_live_windows_on_the_fp32_handover_kernels(plugin, cuda, mode):
 
 
 @pytest.mark.parametrize("B,cin,cout,H,W,up,res", REC_CASES + [(3, 128, 256, 45, 77, False, True), (2, 512, 128, 30, 200, True, False), (1, 64, 128, 90, 130, False, True)])
-def test_two_blocks_per_cu_kernels_are_bit_identical_to_the_one_block_kernels(plugin, cuda, monkeypatch, B, cin, cout, H, W, up, res):
-    """csrc/vae_conv_rec2.hip (two independent 4-wave blocks per CU, default) issues every accumulator's MFMAs in the order of
-    csrc/vae_conv_rec.hip (one 8-wave block per CU, MDTILE_REC_BLOCKS=1): same fp32 output, same record image, bit for bit -- also
-    with many items per block (the ring of step chunks and the input stages run on across item boundaries) and with the start-up
-    skew off / by block index / by the per-CU arrival counter."""
+def test_two_blocks_per_cu_kernels_are_bit_identical_to_the_one_block_kernels(plugin, cuda, B, cin, cout, H, W, up, res):
+    """csrc/vae_conv_rec2.hip (two independent 4-wave blocks per CU) issues every accumulator's MFMAs in the order of
+    csrc/vae_conv_rec.hip (one 8-wave block per CU): same fp32 output, same record image, bit for bit -- also with many items per
+    block (the ring of step chunks and the input stages run on across item boundaries).  The family is named by the call's flags
+    (MDTILE_CONV_REC_ONE_BLOCK / _TWO_BLOCKS); the start-up skew variants are probe switches of the PROBES build only."""
     E = plugin.engine
     torch.manual_seed(cin + 3 * cout + H)
     conv = torch.nn.Conv2d(cin, cout, 3, 1, 1)
@@ -332,22 +332,18 @@ def test_two_blocks_per_cu_kernels_are_bit_identical_to_the_one_block_kernels(pl
     pc = E.PackedConv(conv.weight.detach().to(cuda), conv.bias.detach().to(cuda))
     xrec = E.rec_from_f32(x.to(cuda), None if up else _coef(B, cin, 5).to(cuda))
     rr = torch.randn(B, cout, H, W).to(cuda) if res else None
-    monkeypatch.setenv("MDTILE_REC_BLOCKS", "1")
-    y1, r1 = pc.call_rec(xrec, residual=rr, upsample2x=up, want_f32=True, want_rec=True, rec_coef=out_coef)
-    for skew in ("2", "0", "1"):
-        monkeypatch.setenv("MDTILE_REC_BLOCKS", "2")
-        monkeypatch.setenv("MDTILE_REC2_SKEW", skew)
-        y2, r2 = pc.call_rec(xrec, residual=rr, upsample2x=up, want_f32=True, want_rec=True, rec_coef=out_coef)
-        assert torch.equal(y1, y2), f"fp32 output differs (skew mode {skew}): {_rel(y2, y1)}"
-        assert torch.equal(r1.records(), r2.records()), f"record output differs (skew mode {skew})"
+    y1, r1 = pc.call_rec(xrec, residual=rr, upsample2x=up, want_f32=True, want_rec=True, rec_coef=out_coef, family=E.CONV_REC_ONE_BLOCK)
+    for _ in range(2):      # twice: the per-CU arrival counters of the start-up skew carry over from launch to launch
+        y2, r2 = pc.call_rec(xrec, residual=rr, upsample2x=up, want_f32=True, want_rec=True, rec_coef=out_coef, family=E.CONV_REC_TWO_BLOCKS)
+        assert torch.equal(y1, y2), f"fp32 output differs: {_rel(y2, y1)}"
+        assert torch.equal(r1.records(), r2.records()), "record output differs"
 
 
 @pytest.mark.parametrize("cin,cout,H,W,up,res", [(128, 128, 1200, 1056, False, True), (128, 128, 1200, 1056, False, False), (64, 128, 1088, 1056, True, False)])
-def test_many_items_per_block_and_the_start_up_stagger(plugin, cuda, monkeypatch, cin, cout, H, W, up, res):
+def test_many_items_per_block(plugin, cuda, cin, cout, H, W, up, res):
     """Launches of more than six item rounds per CU (the persistent loop runs long: ring slots, input stages and -- for a conv2 -- the
     residual rows that the epilogue of item i loads into the accumulators of item i + 1 all run on across item boundaries), against torch
-    fp32; and the same launch with the start-up stagger of the persistent blocks on (MDTILE_REC_STAGGER_PCT, csrc/vae_conv_rec.hip:
-    stagger_start -- a delay only): bit for bit the same output."""
+    fp32, one-block family named explicitly."""
     E = plugin.engine
     torch.manual_seed(cin + cout + H)
     conv = torch.nn.Conv2d(cin, cout, 3, 1, 1)
@@ -357,28 +353,22 @@ def test_many_items_per_block_and_the_start_up_stagger(plugin, cuda, monkeypatch
     pc = E.PackedConv(conv.weight.detach().to(cuda), conv.bias.detach().to(cuda))
     xrec = E.rec_from_f32(x.to(cuda), None)
     rr = torch.randn(1, cout, H, W).to(cuda) if res else None
-    monkeypatch.setenv("MDTILE_REC_BLOCKS", "1")
-    monkeypatch.setenv("MDTILE_REC_STAGGER_PCT", "0")
-    y0, r0 = pc.call_rec(xrec, residual=rr, upsample2x=up, want_f32=True, want_rec=True, rec_coef=out_coef)
+    y0, r0 = pc.call_rec(xrec, residual=rr, upsample2x=up, want_f32=True, want_rec=True, rec_coef=out_coef, family=E.CONV_REC_ONE_BLOCK)
     xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if up else x
     ref = F.conv2d(xin.to(cuda), conv.weight.detach().to(cuda), conv.bias.detach().to(cuda), padding=1)
     if res:
         ref = ref + rr
     assert _rel(y0, ref) <= 5e-5
     assert _rel(r0.to_f32(), _act(ref, out_coef)) <= 5e-5
-    for pct in ("50", "100"):
-        monkeypatch.setenv("MDTILE_REC_STAGGER_PCT", pct)
-        y1, r1 = pc.call_rec(xrec, residual=rr, upsample2x=up, want_f32=True, want_rec=True, rec_coef=out_coef)
-        assert torch.equal(y0, y1) and torch.equal(r0.records(), r1.records()), f"stagger {pct} % changed the output"
 
 
-@pytest.mark.parametrize("blocks", ["1", "2"], ids=["one_block_per_cu", "two_blocks_per_cu"])
-def test_upconv_windows_under_both_kernel_families(plugin, cuda, monkeypatch, blocks):
+@pytest.mark.parametrize("blocks", [4, 8], ids=["one_block_per_cu", "two_blocks_per_cu"])
+def test_upconv_windows_under_both_kernel_families(plugin, cuda, blocks):
     """mdtile_upconv2d_rec_window (per-image window origins inside a larger input image, live-window narrowing of the decoder tiles) through
     the one-block kernel AND the two-blocks-per-CU kernel (csrc/vae_conv_rec2.hip: k_upconv_rec2 tiles the window in 4-row items and reads
     the whole image's pitch): every image's window equals the same pixels of the whole-image call, fp32 and records, bit for bit."""
     E = plugin.engine
-    monkeypatch.setenv("MDTILE_REC_BLOCKS", blocks)
+    assert (E.CONV_REC_ONE_BLOCK, E.CONV_REC_TWO_BLOCKS) == (4, 8)
     torch.manual_seed(8)
     conv = torch.nn.Conv2d(256, 128, 3, 1, 1)
     pc = E.PackedConv(conv.weight.detach().to(cuda), conv.bias.detach().to(cuda))
@@ -388,7 +378,7 @@ def test_upconv_windows_under_both_kernel_families(plugin, cuda, monkeypatch, bl
     coef = _coef(B, 128, 3).to(cuda)
     y_full, r_full = pc.call_rec(xr, upsample2x=True, want_f32=True, want_rec=True, rec_coef=coef)
     y0s, x0s = [0, 15, 6, 11], [19, 0, 7, 13]
-    y_win, r_win = pc.call_rec(xr, upsample2x=True, want_f32=True, want_rec=True, rec_coef=coef, window=(y0s, x0s, h, w))
+    y_win, r_win = pc.call_rec(xr, upsample2x=True, want_f32=True, want_rec=True, rec_coef=coef, window=(y0s, x0s, h, w), family=blocks)
     rf, rw = r_full.records(), r_win.records()
     for b in range(B):
         ys_, xs_ = slice(2 * y0s[b], 2 * (y0s[b] + h)), slice(2 * x0s[b], 2 * (x0s[b] + w))
@@ -398,3 +388,56 @@ def test_upconv_windows_under_both_kernel_families(plugin, cuda, monkeypatch, bl
     with torch.no_grad():
         ref = conv.to(cuda)(F.interpolate(x, scale_factor=2.0, mode="nearest"))
     assert _rel(y_full, ref) < 5e-5
+
+
+DRIP_CASES = [  # B, cin, cout, H, W, residual, want_f32, coef
+    (1, 128, 128, 16, 32, False, True, True),        # one pixel tile: two 64-cout items, one per block -- only the un-dripped final epilogue runs
+    (1, 128, 128, 17, 45, True, True, True),         # ragged rows and columns (rows past H: slots that issue no stores -> the uncounted wait)
+    (2, 256, 128, 40, 36, True, True, True),         # batch 2, NK = 16 (two trips after the slot trip)
+    (1, 512, 512, 24, 40, True, True, True),         # 8 cout blocks of 64, NK = 32
+    (1, 128, 128, 1200, 1056, True, True, True),     # ~10 items per block: conv2 (fp32 + records + residual), every slot kind, many swaps
+    (1, 128, 128, 1200, 1056, False, False, True),   # conv1: records only (no fp32 stores, zero start values)
+    (1, 256, 128, 700, 1000, False, True, False),    # fp32 + raw records (no activation), no residual
+    (1, 128, 256, 333, 517, True, True, True),       # odd sizes, 4 cout blocks
+    (3, 128, 128, 278, 278, True, False, True),      # three stacked tiles as the 8K decode launches them; records + residual, no fp32
+]
+
+
+@pytest.mark.parametrize("B,cin,cout,H,W,res,f32,act", DRIP_CASES)
+def test_dripped_epilogue_kernel_is_bit_identical_to_the_one_block_kernel(plugin, cuda, B, cin, cout, H, W, res, f32, act):
+    """csrc/vae_conv_recd.hip (64-cout items, two accumulator sets per wave, the previous item's epilogue issued in slots between the
+    K-steps of the running one; MDTILE_CONV_REC_DRIP) against csrc/vae_conv_rec.hip's one-block kernel: every accumulator sees the same
+    MFMAs in the same order from the same start value, so fp32 output and record image agree bit for bit -- also across many item
+    boundaries (register-set swaps, residual rows loaded into the sealed set, counted vmcnt waits)."""
+    E = plugin.engine
+    torch.manual_seed(cin + 3 * cout + H)
+    conv = torch.nn.Conv2d(cin, cout, 3, 1, 1)
+    x = torch.randn(B, cin, H, W)
+    out_coef = _coef(B, cout, 11).to(cuda) if act else None
+    pc = E.PackedConv(conv.weight.detach().to(cuda), conv.bias.detach().to(cuda))
+    xrec = E.rec_from_f32(x.to(cuda), _coef(B, cin, 5).to(cuda))
+    rr = torch.randn(B, cout, H, W).to(cuda) if res else None
+    y1, r1 = pc.call_rec(xrec, residual=rr, want_f32=f32, want_rec=True, rec_coef=out_coef, family=E.CONV_REC_ONE_BLOCK)
+    for _ in range(2):
+        y2, r2 = pc.call_rec(xrec, residual=rr, want_f32=f32, want_rec=True, rec_coef=out_coef, family=E.CONV_REC_DRIP)
+        if f32:
+            assert torch.equal(y1, y2), f"fp32 output differs: {_rel(y2, y1)}"
+        assert torch.equal(r1.records(), r2.records()), "record output differs"
+    if f32 and H * W < 200000:
+        ref = F.conv2d(x.to(cuda), conv.weight.detach().to(cuda), conv.bias.detach().to(cuda), padding=1) if not act else None
+        if ref is not None:
+            assert _rel(y2, ref + rr if res else ref) <= 5e-5
+
+
+def test_dripped_epilogue_fp32_only_output(plugin, cuda):
+    """fp32 output alone (no record image): only the A half of the slots issues stores."""
+    E = plugin.engine
+    torch.manual_seed(5)
+    conv = torch.nn.Conv2d(128, 128, 3, 1, 1)
+    x = torch.randn(1, 128, 600, 800)
+    pc = E.PackedConv(conv.weight.detach().to(cuda), conv.bias.detach().to(cuda))
+    xrec = E.rec_from_f32(x.to(cuda))
+    rr = torch.randn(1, 128, 600, 800).to(cuda)
+    y1, _ = pc.call_rec(xrec, residual=rr, want_f32=True, want_rec=False, family=E.CONV_REC_ONE_BLOCK)
+    y2, _ = pc.call_rec(xrec, residual=rr, want_f32=True, want_rec=False, family=E.CONV_REC_DRIP)
+    assert torch.equal(y1, y2)

@@ -91,7 +91,37 @@ def test_dma_protocol_in_the_device_assembly():
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asm_guard.py")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout
-    assert r.stdout.count(" ok") == 10, r.stdout      # 2 streaming 1x1 + 3 record (one block per CU) + 2 record (two blocks per CU) + 3 attention
+    assert r.stdout.count(" ok") == 11, r.stdout      # 2 streaming 1x1 + 3 record (one block per CU) + 2 record (two blocks per CU) + 1 record (dripped epilogue) + 3 attention
+
+
+def test_environment_switches_of_the_shipping_library(built_lib):
+    """Boundary contract (no global mutable state except the plan): the shipping libmdtile.so reads THREE environment
+    variables, once, when it is loaded / a shard context is made; every probe switch (MDTILE_REC_DBG, _STAMPS, _GRID, _BLOCKS, _PERSIST,
+    _STAGGER_PCT, MDTILE_REC2_*, MDTILE_BLEND_CFG, MDTILE_ATTN_SPLIT, MDTILE_C1X1_STREAM) lives in the PROBES twin only
+    (csrc/common.h: probe_env; mdtile/build.py: build_probes) -- none of their names is in the binary, no launch path calls getenv, no
+    pointer is ever read from the environment.  The Python host reads a fixed list of user switches."""
+    out = subprocess.run(["strings", built_lib.LIB_PATH], capture_output=True, text=True).stdout
+    in_lib = sorted(set(re.findall(r"^MDTILE_[A-Z0-9_]+$", out, flags=re.M)))
+    assert in_lib == ["MDTILE_ATTN_MODE", "MDTILE_CONV_MODE", "MDTILE_SHARD_TRANSPORT"], in_lib
+    assert "MDTILE_REC_DBG" not in out and "MDTILE_REC_STAMPS" not in out and "MDTILE_REC2_CENSUS" not in out
+    csrc = os.path.join(ROOT, "multidiffusion-upscaler-for-automatic1111_amd", "csrc")
+    getenv_sites = []
+    for f in sorted(x for x in os.listdir(csrc) if x.endswith((".hip", ".h"))):
+        for i, line in enumerate(open(os.path.join(csrc, f)), 1):
+            if re.search(r"\bgetenv\(", line) and "probe_env" not in line:
+                getenv_sites.append((f, re.findall(r'"(MDTILE_[A-Z0-9_]+)"', line)))
+    assert sorted(n for _, names in getenv_sites for n in names) == ["MDTILE_ATTN_MODE", "MDTILE_CONV_MODE", "MDTILE_SHARD_TRANSPORT"], getenv_sites
+    allowed_py = {"MDTILE_LIVE_WINDOW", "MDTILE_TILE_BATCH", "MDTILE_SP_ESTIMATOR", "MDTILE_SLOW_REC", "MDTILE_REC", "MDTILE_FUSE_GN",
+                  "MDTILE_SHARD_PROBE", "MDTILE_SHARD_TORCH", "MDTILE_SKIP_ASM_GUARD"}
+    plug = os.path.join(ROOT, "multidiffusion-upscaler-for-automatic1111_amd")
+    seen = set()
+    for dp, _, files in os.walk(plug):
+        for f in files:
+            if f.endswith(".py"):
+                for line in open(os.path.join(dp, f)):
+                    if "environ" in line:
+                        seen.update(re.findall(r"MDTILE_[A-Z0-9_]+", line))
+    assert seen <= allowed_py, seen - allowed_py
 
 
 def test_no_cpu_fallback(built_lib):

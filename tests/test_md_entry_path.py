@@ -2,7 +2,7 @@
 `kdiff_forward` / `ddim_forward` -> `repeat_func` -> `repeat_tensor` / `repeat_cond_dict` -> blend, three sampler steps with a
 stand-in UNet that depends on tile content, sigma, c_crossattn rows, c_concat (latent-sized => sliced per bbox) and SDXL's vector.
 
-  * CPU (`-m "not gpu"`): the upstream delegate itself (tile_methods/multidiffusion.py:15-29, 52-129 under oracle/stub_host.py) against
+  * CPU (`-m "not gpu"`): the upstream delegate itself (tile_methods/multidiffusion.py:15-29, 52-129 under hostsim/stub_host.py) against
     oracle/entry_oracle.py AND the committed tests/golden/entry.npz -- pins the restatement;
   * GPU (`-m gpu`): this repo's delegate (mdtile engine) against the oracle and the upstream-made goldens, torch.equal.
 """

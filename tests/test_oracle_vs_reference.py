@@ -1,5 +1,5 @@
 """Pins the oracle: runs the UPSTREAM reference code itself (imported verbatim from /root/reference under
-oracle/stub_host.py) next to the restatement on the same seeded inputs.  Skipped where /root/reference is not mounted
+hostsim/stub_host.py) next to the restatement on the same seeded inputs.  Skipped where /root/reference is not mounted
 (the GPU box) -- there the committed golden vectors (test_oracle_golden.py) carry the pin."""
 import pytest
 import torch

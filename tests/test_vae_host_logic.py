@@ -137,6 +137,64 @@ def test_sharded_decode_with_a_rank_that_owns_no_tile(fast):
     assert not bad, "\n".join(bad)
 
 
+def _worker_interrupt(rank, world, port, q):
+    """Slow mode over two ranks; rank 1 sees state.interrupted in the middle of the lockstep sweep (after its 3rd tile segment).  Both ranks
+    must leave the sweep at the SAME pooled barrier (the interrupt rides in the barrier's head exchange), skip the gather together and
+    return -- before the fix rank 1's 2-float agreement all-reduce paired with rank 0's head exchange: a spurious NaN error on one side
+    and a hang in allreduce_stats on the other."""
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        import datetime
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+        torch.set_num_threads(1)
+        from hostsim import ldm_decoder as ld
+        dec = ld.make_decoder(0, small=True)
+        torch.manual_seed(2)
+        z = torch.randn(1, 4, 40, 56)
+        hook = _hook(dec, 16, True, False)
+        hook.shard = (rank, world)
+        hook.gather_to = 0
+        from modules.shared import state
+        state.interrupted = False
+        calls = [0]
+        orig = hook._run_until_norm
+
+        def counted(steps, st):
+            calls[0] += 1
+            if rank == 1 and calls[0] == 3:
+                state.interrupted = True
+            return orig(steps, st)
+
+        hook._run_until_norm = counted
+        with torch.no_grad():
+            out = hook(z)
+        assert out.shape == (1, 3, 320, 448) and torch.isfinite(out).all()      # the host's cheap approximation: no tile finished
+        assert calls[0] < 40, f"rank {rank} kept decoding after the interrupt ({calls[0]} segments)"
+        dist.barrier()
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_interrupt_in_multi_rank_slow_mode_leaves_the_sweep_on_every_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_interrupt, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    bad = [f"rank {r}: {msg}" for r, msg in results if msg != "ok"]
+    assert not bad, "\n".join(bad)
+
+
 # ---- live-window narrowing of the fast-mode decoder tiles (scripts/tilevae.py: live_windows, _live_plan) -----------------------------
 def _rec_hook(net, ts, fast=True, rec_convs=True):
     import torch_engine as te

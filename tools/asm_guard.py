@@ -10,7 +10,8 @@ device assembly and checks the emitted instruction stream instead:
     * every s_barrier is directly preceded (ignoring scalar ALU) by an s_waitcnt, and the vmcnt values those waits count are exactly
       the ones the source asks for: {0, 5} in k_conv3x3_rec (the 5 input pieces of the next K-step may stay in flight at dy = 1),
       {0} in k_upconv_rec and k_attn_bf16x3 (lgkmcnt-only waits -- LDS hand-overs that consume no DMA -- are reported separately),
-      {0, 2, 3, 4} in k_conv3x3_rec2 and {0, 6, 7, 8, 9} in k_upconv_rec2 (one counted wait per step position, csrc/vae_conv_rec2.hip)
+      {0, 2, 3, 4} in k_conv3x3_rec2 and {0, 6, 7, 8, 9} in k_upconv_rec2 (one counted wait per step position, csrc/vae_conv_rec2.hip),
+      {0, 2, 5, 15} in k_conv3x3_recd (csrc/vae_conv_recd.hip: the dripped epilogue's slot traffic may stay in flight behind the chunk)
     * MFMA counts per unrolled trip match the source (conv: 36 half-steps x 12; upconv: 24 combo-steps x 12; attention: 24 / slab)
 usage: python tools/asm_guard.py   (exit code 0 = ok; prints one line per kernel)      -- also run by tests/test_host_abi.py
 """
@@ -116,6 +117,7 @@ def main() -> int:
     errs = []
     rec = kernels(device_asm(os.path.join(CSRC, "vae_conv_rec.hip")))
     rec2 = kernels(device_asm(os.path.join(CSRC, "vae_conv_rec2.hip")))
+    recd = kernels(device_asm(os.path.join(CSRC, "vae_conv_recd.hip")))
     att = kernels(device_asm(os.path.join(CSRC, "vae_attn_bf16x3.hip")))
     c11 = kernels(device_asm(os.path.join(CSRC, "vae_conv1x1_bf16x3.hip")))
     plan = [
@@ -127,6 +129,8 @@ def main() -> int:
         # two blocks per CU: one counted wait per step position (tools/rec2_protocol_sim.py derives and checks the values)
         (rec2, "k_conv3x3_rec2ILi2ELi2ELi4", dict(dma_min=8, barrier_vmcnt=[0, 2, 3, 4], mfma_multiple=12)),
         (rec2, "k_upconv_rec2E", dict(dma_min=8, barrier_vmcnt=[0, 6, 7, 8, 9], mfma_multiple=12)),
+        # dripped epilogue: vmcnt(5) at dy = 1, and behind a slot phase a lower bound of the slot's own memory instructions (15 / 2)
+        (recd, "k_conv3x3_recdE", dict(dma_min=8, barrier_vmcnt=[0, 2, 5, 15], mfma_multiple=12)),
         (att, "k_attn_bf16x3ILi512", dict(dma_min=8, barrier_vmcnt=[0], mfma_multiple=6)),
         (att, "k_attn_bf16x3ILi256", dict(dma_min=8, barrier_vmcnt=[0], mfma_multiple=6)),
         (att, "k_attn_bf16x3ILi128", dict(dma_min=8, barrier_vmcnt=[0], mfma_multiple=6)),
