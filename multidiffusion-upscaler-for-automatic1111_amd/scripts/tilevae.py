@@ -656,7 +656,11 @@ class VAEHook:
                 frozen = self.estimate_group_norm(zs, steps)
 
         rank, world = self.shard
-        mine = list(range(len(in_bboxes))) if world == 1 else list(range(rank, len(in_bboxes), world))
+        owner = [0] * len(in_bboxes)
+        if world > 1:
+            from mdtile import sharding as _sh
+            owner = _sh.deal_tiles(in_bboxes, world)      # by tile area (mdtile/sharding.py: deal_tiles), the same list on every rank
+        mine = [i for i in range(len(in_bboxes)) if owner[i] == rank] if world > 1 else list(range(len(in_bboxes)))
         tiles = {i: TileState(E.gather_rect(z, b[0], b[2], b[1] - b[0], b[3] - b[2])) for i, b in enumerate(in_bboxes) if i in set(mine)}
         result = None
         interrupted = False
@@ -834,7 +838,7 @@ class VAEHook:
                 result = torch.zeros((N, 3 if self.is_decoder else 2 * int(getattr(net, "z_channels", 4)),
                                       *((height * 8, width * 8) if self.is_decoder else (height // 8, width // 8))), device=dev, dtype=torch.float32)
             if result is not None:
-                sharding.gather_tiles_to_root(result, out_bboxes, lambda i: i % world, rank, self.gather_to)
+                sharding.gather_tiles_to_root(result, out_bboxes, lambda i: owner[i], rank, self.gather_to)
         self.last_seconds = time() - t0
         if interrupted and result is not None:
             return result.to(dtype)          # upstream hands back what is finished (:644-647)

@@ -12,6 +12,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "multidiffusion-upscaler-for-automatic1111_amd"))
 sys.path.insert(0, ROOT)
 import mdtile as E
+DBG = None
+if "--kloop" in sys.argv:      # K loops alone (MDTILE_REC_DBG=1 of the PROBES twin: no epilogue / no slots, nothing is written)
+    DBG = "1"
+if "--dbg" in sys.argv:        # csrc/vae_conv_recd.hip: 2 no activation arithmetic | 4 no record stores | 8 no fp32 stores | 16 no residual loads
+    DBG = sys.argv[sys.argv.index("--dbg") + 1]
+if DBG is not None:
+    sys.path.insert(0, os.path.join(ROOT, "probes"))
+    import _probes_lib
+    _probes_lib.use(E)
+    os.environ["MDTILE_REC_DBG"] = DBG
 
 dev = torch.device("cuda:0")
 SHAPES = [  # cin, cout, H, W

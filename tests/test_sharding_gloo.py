@@ -184,3 +184,27 @@ def _worker_bringup(rank, world, port, q):
 @pytest.mark.parametrize("world", [2, 3])
 def test_checked_bringup_votes_and_falls_back(world):
     _run(_worker_bringup, world)
+
+
+def test_cost_aware_tile_deal():
+    """mdtile/sharding.py: deal_tiles -- VAE tiles by area (longest-processing-time greedy), the same owner list on every rank.  The 8K
+    decode's 4 x 4 grid (nine 278 x 278, three 278 x 256, three 256 x 278, one 256 x 256 latent tiles) on 4 ranks: round-robin gives ranks
+    0-2 a whole column of large tiles each (2 % over the mean on the heaviest rank), the deal 3-2-2-2 (0.1 %); on 8 ranks every rank gets
+    two tiles (nine large ones: one pair of them is unavoidable); equal tiles degenerate to round-robin."""
+    from mdtile import sharding
+    from oracle import vae_oracle as vo
+    ins, _ = vo.split_tiles(1024, 1024, 256)
+    area = [(b[1] - b[0]) * (b[3] - b[2]) for b in ins]
+    assert sorted(area, reverse=True)[:9] == [278 * 278] * 9 and len(ins) == 16
+    mean4 = sum(area) / 4
+    rr = max(sum(area[i] for i in range(r, 16, 4)) for r in range(4))
+    own = sharding.deal_tiles(ins, 4)
+    loads = [sum(a for a, o in zip(area, own) if o == r) for r in range(4)]
+    assert sorted(sum(1 for a, o in zip(area, own) if o == r and a == 278 * 278) for r in range(4)) == [2, 2, 2, 3]
+    assert max(loads) / mean4 < 1.002 < 1.015 < rr / mean4
+    own8 = sharding.deal_tiles(ins, 8)
+    assert sorted(own8) == sorted(list(range(8)) * 2)
+    assert max(sum(a for a, o in zip(area, own8) if o == r) for r in range(8)) == 2 * 278 * 278
+    same = [[0, 64, 0, 64]] * 7
+    assert sharding.deal_tiles(same, 3) == [0, 1, 2, 0, 1, 2, 0]
+    assert sharding.deal_tiles(ins, 1) == [0] * 16

@@ -86,7 +86,9 @@ def _worker(rank, world, port, fast, q, hw=(40, 56)):
             err = (out - ref).abs().max().item() / ref.abs().max().item()
             assert err < 2e-4, f"assembled image on rank 0: rel err {err}"
         ins, outs = vo.split_tiles(hw[0], hw[1], 16, True)
-        mine = list(range(rank, len(ins), world))
+        from mdtile import sharding
+        owner = sharding.deal_tiles(ins, world)
+        mine = [i for i in range(len(ins)) if owner[i] == rank]
         assert mine or hw != (40, 56), "the default geometry must give every rank a tile"
         for i in mine:
             ob = outs[i]
