@@ -24,17 +24,23 @@
 //
 // K loop: the protocol of k_conv3x3_rec -- phases (K-step k, tap row dy) of three steps dx (12 MFMAs per wave and step), input
 // stage [hl][kg][18][34] records x 2, weight chunks [hl][dx][mt 2][lane] (12 KB) in a 3-slot ring (slot = dy), ONE barrier per
-// phase behind its dx = 0 step, chunk ph + 2 and the next K-step's input requested behind the barrier, the next item's first
-// operands in the item's last phase.  One trip = 4 K-steps = 12 phases = 36 steps, fully unrolled (cin % 64 == 0).  The 8 slots of an
-// item sit in the dy = 1 / dy = 2 phases of its FIRST trip, position i = 2 k + dy - 1, for the wave's four (m-tile, row) units u = i / 2:
-//     i even: + bias, fp32 stores, activation + split + record stores of channels 0-7 of the lane's 16
-//     i odd : the same for channels 8-15, then the residual row of item i+1 into the unit's registers
-// (cin = 128: the second trip is left for the last residual row to land; the code of a trip stays ~40 KB).
-// vmcnt (gfx9 counts loads AND stores in it, in order): a phase's site issues chunk ph + 2 FIRST and its slot's stores / loads
-// AFTER it, and the wait in front of the next barrier is vmcnt(N), N = a LOWER BOUND of the memory instructions that slot has
-// issued (18 / 16 -> 15, what the 4-bit field takes; 2; else 0) -- the chunk has landed, the slot's traffic may stay in flight for
-// a second phase (an HBM write acknowledge under a chip-wide 3 TB/s of epilogue traffic is not back within one 1.3 us phase).
-// dy = 0 phases carry no slot: there the 5 input pieces of the next K-step are the youngest and vmcnt(5) at dy = 1 is as before.
+// phase, chunk ph + 2 and the next K-step's input requested behind it, the next item's first operands in the item's last phase.
+// An item's K loop = the SLOT TRIP (K-steps 0-3, 36 steps unrolled) + plain trips of two K-steps (18 steps unrolled; cin % 32 == 0,
+// cin >= 128).  The 8 slots of an item sit in the dy = 1 / dy = 2 phases of the slot trip, position i = 2 k + dy - 1, for the
+// wave's four (m-tile, row) units u = i / 2, each slot in THREE pieces behind the phase's three MFMA blocks:
+//     i even: + bias, fp32 stores | activation of channels 0-7 of the lane's 16 | split + record stores of them
+//     i odd : activation of channels 8-15 | split + record stores (+ the item's zero border cells) | residual row of item i+1 -> registers
+// (a dy = 0 phase spreads the 5 input pieces of the next K-step over its three pieces instead).  No piece is longer than the
+// 12-MFMA block the wave's SIMD partner covers it with; the two waves of a SIMD (w and w + 4, probes/simd_map_probe.cpp) run the
+// SAME instruction stream half a step apart: waves 0-3 pass a phase's barrier BEHIND its dx = 0 block, waves 4-7 IN FRONT of it --
+// released together, one starts with its piece and the other with its block, and they alternate until the next barrier.
+// vmcnt (gfx9 counts loads AND stores in it, in order): a phase issues chunk ph + 2 FIRST and its slot's stores / loads AFTER it,
+// and the wait in front of the next barrier is vmcnt(N), N = a LOWER BOUND of the memory instructions that slot has issued
+// (18 / 16 -> 15, what the 4-bit field takes; 2; else 0) -- the chunk has landed, the slot's traffic may stay in flight for a
+// second phase.  dy = 0 phases carry no slot: there the 5 input pieces are the youngest and vmcnt(5) at dy = 1 is as before.
+// hipcc: the slot code must not share a LOOP with the residual loads of an earlier trip, nor sit in a wave-group branch: it then
+// assumes those rows are still in flight when a slot touches the registers and waits with ITS count (blind to the LDS-DMA) --
+// vmcnt(0) in the middle of a slot (profiles/r5a, r5b).  Hence the separate unrolled slot trip and one stream for all waves.
 //
 // Upstream call sites replaced: conv1 / conv2 tasks of scripts/tilevae.py:115-136 with the custom_group_norm + SiLU in front of
 // the NEXT conv (:218-245, :102-104) and the queue's add_res (:612-616) -- the same set as vae_conv_rec.hip.
@@ -56,7 +62,7 @@ constexpr int D_TH = 16, D_ROWS = D_TH + 2, D_COLS = 34;
 constexpr int ECD = 16;                  // float4 stride between [bias | a | s] of a constants buffer (64 couts x 4 B = 256 B each)
 constexpr int ECD_REC = 3 * ECD;         // records of one constants buffer
 
-constexpr int D_TK = 4;                  // K-steps of one unrolled trip
+constexpr int D_TK = 4;                  // K-steps of the slot trip
 // slot of phase p (0 .. 11) of an item's first trip: position i = 2 k + dy - 1 of the dy = 1 / 2 phases, 8 slots
 __host__ __device__ constexpr int slot_pos(int p) { return p % 3 == 0 ? -1 : 2 * (p / 3) + p % 3 - 1; }
 __host__ __device__ constexpr int slot_kind(int p) { return slot_pos(p) < 0 ? 0 : 1 + slot_pos(p) % 2; }   // 0 none, 1: A + R0, 2: R1 + E
@@ -80,6 +86,8 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_recd(const ConvRParams P) {
     const int Hp = P.H + 2, Wp = rec_pitch(P.W), Pn = P.Cin >> 3, PnO = P.Cout >> 3;
     const size_t plane = (size_t)Hp * Wp;
     const int NCB2 = P.Cout >> 6;
+    // probing (PROBES twin only, MDTILE_REC_DBG): 1 K loop alone | 2 no activation arithmetic | 4 no record stores | 8 no fp32 stores |
+    // 16 no residual loads | 32 the barriers do not wait for the DMA (wrong operands, timing only) | 64 no operand DMA at all
     const int dbg = pdbg(P.dbg);
 
     // work -> (sample, pixel tile, 64-cout block): as in k_conv3x3_rec (`work % 8` is this block's XCD for all its items: every cout
@@ -116,10 +124,12 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_recd(const ConvRParams P) {
             ioff[i] = (unsigned)(((size_t)g * plane + (size_t)pr * Wp + pc) * 16);
         }
     };
-    auto issue_input = [&](const DItem& it, const unsigned (&ioff)[IS::PW], int k, int stage) {
+    auto issue_input = [&](const DItem& it, const unsigned (&ioff)[IS::PW], int k, int stage, int i0 = 0, int i1 = IS::PW) {
+        if (dbg & 64) return;
         const char* xb = reinterpret_cast<const char*>(P.x + (size_t)it.b * 2 * Pn * plane);
 #pragma unroll
         for (int i = 0; i < IS::PW; ++i) {
+            if (i < i0 || i >= i1) continue;
             const int di = wave + 8 * i;
             const char* base = xb + ((size_t)(di / IS::HALF_DMA) * Pn + 2 * (size_t)k) * plane * 16;   // wave-uniform
             dma16(base, ioff[i], in_l + stage * IS::PAD + di * 64);
@@ -128,6 +138,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_recd(const ConvRParams P) {
     const unsigned lane16 = lane * 16;
     // chunk (k, dy) of the item's 64 couts: piece p = (hl, dx, mt) -> packed piece (hl, dx, 2 (cb & 1) + mt) of the 128-cout block cb >> 1
     auto issue_weights = [&](const DItem& it, int ph, int ring) {
+        if (dbg & 64) return;
         const char* wsrc = reinterpret_cast<const char*>(P.w + ((size_t)(it.cb >> 1) * P.NK * 3 + ph) * W_SRC);
         const int half2 = (it.cb & 1) * 2;
 #pragma unroll
@@ -203,7 +214,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_recd(const ConvRParams P) {
                 S[m][n][0][4 * g] += tb.x; S[m][n][0][4 * g + 1] += tb.y; S[m][n][0][4 * g + 2] += tb.z; S[m][n][0][4 * g + 3] += tb.w;
             }
         }
-        if (P.y32 && L.ok) {
+        if (P.y32 && L.ok && !(dbg & 8)) {
             const unsigned ro = ((4u * L.kgo) * (unsigned)HW + L.xc) * 4u + (unsigned)(L.y * P.W) * 4u;
             char* const yb32 = reinterpret_cast<char*>(P.y32) + ((size_t)it.b * P.Cout + (size_t)(it.cb * D_MT + m) * 32) * HW4;
             gchar* up = uniform_ptr(yb32);
@@ -214,37 +225,43 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_recd(const ConvRParams P) {
             }
         }
     };
-    // R: activation + split + record stores of 8 of the lane's 16 channels (R = 0 / 1)
-    auto slot_r = [&](f32x16 (&S)[D_MT][D_NROW][1], const DItem& it, const u32x4* ec, int m, int n, int R) {
+    // R: activation (in place), then split + record stores, of 8 of the lane's 16 channels (R = 0 / 1) -- two pieces of a slot
+    auto slot_r_act = [&](f32x16 (&S)[D_MT][D_NROW][1], const u32x4* ec, int m, int n, int R) {
+        if (!has_act || (dbg & 2)) return;
+        unsigned kgo = (unsigned)kg;
+        asm volatile("" : "+v"(kgo));
+        const float4* e4 = reinterpret_cast<const float4*>(ec) + (m * 8 + kgo);
+        f32x2 aq[4], sq[4];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const float4 ta = e4[ECD + 4 * R + 2 * g], ts = e4[2 * ECD + 4 * R + 2 * g];
+            aq[2 * g] = f32x2{ta.x, ta.y}; aq[2 * g + 1] = f32x2{ta.z, ta.w};
+            sq[2 * g] = f32x2{ts.x, ts.y}; sq[2 * g + 1] = f32x2{ts.z, ts.w};
+        }
+        act8(S[m][n][0], 8 * R, aq, sq);
+    };
+    auto slot_r_store = [&](f32x16 (&S)[D_MT][D_NROW][1], const DItem& it, int m, int n, int R) {
         if (!P.yrec) return;
         const Lane L = lane_of(it, n);
         if (!L.ok) return;
-        const float4* e4 = reinterpret_cast<const float4*>(ec) + (m * 8 + L.kgo);
         char* const yr = reinterpret_cast<char*>(P.yrec) + ((size_t)it.b * 2 * PnO + (size_t)(it.cb * D_MT + m) * 4) * pl16;
         const unsigned rrow = (L.kgo * (unsigned)plane + (L.xc + (unsigned)REC_COL0)) * 16u + (unsigned)((L.y + 1) * Wp) * 16u;
-        {
-        if (has_act) {
-            f32x2 aq[4], sq[4];
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const float4 ta = e4[ECD + 4 * R + 2 * g], ts = e4[2 * ECD + 4 * R + 2 * g];
-                aq[2 * g] = f32x2{ta.x, ta.y}; aq[2 * g + 1] = f32x2{ta.z, ta.w};
-                sq[2 * g] = f32x2{ts.x, ts.y}; sq[2 * g + 1] = f32x2{ts.z, ts.w};
-            }
-            act8(S[m][n][0], 8 * R, aq, sq);
-        }
         gchar* const yp = uniform_ptr(yr + (size_t)(2 * R) * pl16), *const ypl = uniform_ptr(yp + lo_half);
         u32x4 hi, lo;
         split8p(S[m][n][0], 8 * R, hi, lo);
         const size_t at = (size_t)(rrow + 16u);
-        *(MDT_GLOBAL u32x4*)(yp + at) = hi;
-        *(MDT_GLOBAL u32x4*)(ypl + at) = lo;
+        if (!(dbg & 4)) {
+            *(MDT_GLOBAL u32x4*)(yp + at) = hi;
+            *(MDT_GLOBAL u32x4*)(ypl + at) = lo;
+        } else {
+            asm volatile("" ::"v"(hi), "v"(lo));      // (probing: the split stays, its stores go)
         }
     };
     // zero border of the record image: this block owns the border cells next to its edge pixels.  Coordinates only, no accumulator data:
     // ONE rolled loop per item over the wave's 2 rows x 2 m-tiles x 2 record pairs (edge tiles only; issued with the item's last R slot)
     auto zero_border = [&](const DItem& it) {
         if (!P.yrec) return;
+        if (!(it.x0 == 0 || it.x0 + 32 >= P.W || it.y0 == 0 || it.y0 + D_TH >= P.H)) return;      // (wave-uniform: interior tiles own no border cell)
         const Lane L0 = lane_of(it, 0);
         if (!(L0.x < P.W)) return;
         const bool left = L0.x == 0, right = L0.x + 1 == P.W;
@@ -289,15 +306,14 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_recd(const ConvRParams P) {
         R.x_ok = R.x < P.W;
         return R;
     };
+    // (loads only: without a residual the start values are zeroed at the item top -- a zeroing `else` here made hipcc merge the two
+    // paths with v_cndmask behind a vmcnt(0) of its own, i.e. wait for the rows right where they were requested)
+    const bool res_on = P.res != nullptr && !(dbg & 1) && !(dbg & 16);
     auto slot_e = [&](f32x16 (&S)[D_MT][D_NROW][1], const DItem& it, bool on, int m, int n) {
-        if (P.res != nullptr && !(dbg & 1)) {
-            if (!on) return;
+        if (res_on && on) {
             const ResRows<D_NROW> R = res_rows(it);
             if (n == 0) residual_into_acc<D_NROW, D_MT, 1>(P.res, P.Cout, HW, P.H, P.W, kg, R, m, 0, S);
             else residual_into_acc<D_NROW, D_MT, 1>(P.res, P.Cout, HW, P.H, P.W, kg, R, m, 1, S);
-        } else {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) S[m][n][0][q] = 0.0f;
         }
     };
 
@@ -325,6 +341,10 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_recd(const ConvRParams P) {
             slot_e(sealed, cur, true, m, n);
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[m][n][0][q] = 0.0f;
+            if (!res_on) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) sealed[m][n][0][q] = 0.0f;
+            }
         }
 
     while (true) {
@@ -341,96 +361,120 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_recd(const ConvRParams P) {
                 acc[m][n][0] = sealed[m][n][0];
                 sealed[m][n][0] = t;
             }
+        if (!res_on) {
+#pragma unroll
+            for (int m = 0; m < D_MT; ++m)
+#pragma unroll
+                for (int n = 0; n < D_NROW; ++n)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[m][n][0][q] = 0.0f;
+        }
         load_fw(0, 0, 0);
         load_fx(0, 0, 0, 0);
         const int work_n = next_valid(work + gridDim.x, nxt);
         const bool has_next = work_n < total;
-        unsigned ioff_n[IS::PW];
-        if (has_next) make_ioff(nxt, ioff_n);
         const u32x4* const ec_prev = ec_l + (par ^ 1) * ECD_REC;
         const bool drip = have_prev && !(dbg & 1);
 
-        for (int k8 = 0; k8 < P.NK; k8 += D_TK) {
-            const bool first = k8 == 0;
-#pragma unroll
-            for (int t = 0; t < 9 * D_TK; ++t) {
-                const int kk = t / 9, dy = (t / 3) % 3, dx = t % 3, pl_ = t / 3;      // pl_: phase of the trip, 0 .. 11
-                const int k = k8 + kk, ph = k * 3 + dy;
-                const int ws = t & 1;
-                // ---- the NEXT step's fragments go out first
-                MDT_PIN();
-                if (t < 9 * D_TK - 1) {
-                    const int t1 = t + 1;
-                    load_fw(ws ^ 1, (t1 / 3) % 3, t1 % 3);
-                    load_fx(ws ^ 1, (t1 / 9) & 1, (t1 / 3) % 3, t1 % 3);
-                } else if (k8 + D_TK < P.NK) {
-                    load_fw(ws ^ 1, 0, 0);
-                    load_fx(ws ^ 1, 0, 0, 0);
-                }
-                MDT_PIN();
-                // ---- this step's MFMAs: term-major over the wave's four accumulators
-#pragma unroll
-                for (int term = 0; term < 3; ++term)
-#pragma unroll
-                    for (int n = 0; n < D_NROW; ++n)
-#pragma unroll
-                        for (int m = 0; m < D_MT; ++m)
-                            acc[m][n][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ws][m][term == 0 ? 1 : 0], fx[ws][n][term == 1 ? 1 : 0],
-                                                                                   acc[m][n][0], 0, 0, 0);   // w_lo x_hi, w_hi x_lo, w_hi x_hi
-                MDT_PIN();
-                if (dx == 0) {
-                    // in flight, oldest first: [the slot traffic of phase ph-2] chunk ph+1 (requested behind the previous barrier), then
-                    // EITHER the slot traffic of phase ph-1 (N memory instructions, see the file header) OR -- at dy = 1 -- the 5 input
-                    // pieces of K-step k+1: those youngest ones may stay in flight one more phase, everything older has to be in
-                    constexpr int PL = 3 * D_TK;
-                    const int pp = (pl_ + PL - 1) % PL;                          // the phase before this one (phase 0: the last one of the trip before)
-                    const int pk = slot_kind(pp);
-                    const bool pfirst = pl_ > 0 ? first : k8 == D_TK;            // ... and whether it carried its slot (first trip only)
-                    bool counted = false;
-                    if (pk != 0 && pfirst) {
-                        const bool yok = drip && prv.y0 + wave * D_NROW + (slot_unit(pp) & 1) < P.H;      // wave-uniform: did the slot issue its stores
-                        const bool big = pk == 1 ? (yok && P.y32 != nullptr) : (P.res != nullptr && has_next && !(dbg & 1));      // >= 16 of them
-                        if (big) { MDT_VMCNT(15); counted = true; }
-                        else if (yok && P.yrec != nullptr) { MDT_VMCNT(2); counted = true; }
-                    }
-                    if (!counted) {
-                        if (dy == 1 && k + 1 < P.NK) MDT_VMCNT(5);
-                        else MDT_VMCNT(0);
-                    }
-                    asm volatile("" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    asm volatile("" ::: "memory");
-                }
-                // requests of this phase, staggered between the two waves that share a SIMD (w and w + 4): waves 0-3 right behind the
-                // barrier, waves 4-7 one step later.  Order inside a phase: chunk ph+2, then EITHER the slot (previous item's results
-                // out / next item's residual in; dy = 1, 2) OR the input stage of K-step k+1 (dy = 0) -- the youngest requests.
-                if ((dx == 0 && wave < 4) || (dx == 1 && wave >= 4)) {
-                    if (ph + 2 < nph) issue_weights(cur, ph + 2, (dy + 2) % 3);
-                    const int sk = slot_kind(pl_), su = sk ? slot_unit(pl_) : 0, sm = su >> 1, sn = su & 1;
-                    if (sk != 0 && first) {
-                        if (sk == 1) {
-                            if (drip) {
-                                slot_a(sealed, prv, ec_prev, sm, sn);
-                                slot_r(sealed, prv, ec_prev, sm, sn, 0);
-                            }
-                        } else {
-                            if (drip) {
-                                slot_r(sealed, prv, ec_prev, sm, sn, 1);
-                                if (su == 3) zero_border(prv);
-                            }
-                            slot_e(sealed, nxt, has_next, sm, sn);
-                        }
-                    }
-                    if (dy == 0 && k + 1 < P.NK) issue_input(cur, ioff, k + 1, (kk + 1) & 1);
-                    if (kk == D_TK - 1 && dy == 2 && k + 1 == P.NK && has_next) {
-                        // last phase of the item: ring slots 0 / 1 and input stage 0 are out of use -> the next item's first operands
-                        issue_input(nxt, ioff_n, 0, 0);
-                        issue_weights(nxt, 0, 0);
-                        issue_weights(nxt, 1, 1);
-                        issue_consts(nxt, par ^ 1);
-                    }
-                }
+        // the requests of a phase in three pieces, one behind each of its MFMA blocks (see the file header)
+        //   piece 0: chunk ph+2, then the first third of EITHER the slot (dy = 1, 2 of the slot trip) OR the next K-step's input stage
+        //   (dy = 0); pieces 1, 2: the rest of it.  Per wave the order is chunk -> slot / input, all in front of the next phase's wait.
+        auto piece = [&](int sp, int qdy, int kq, int j, bool can_be_last) {      // sp: phase of the slot trip (0 .. 11) or -1, tap row, K-step, piece j
+            const int qph = kq * 3 + qdy;
+            const int sk = sp >= 0 ? slot_kind(sp) : 0, su = sk ? slot_unit(sp) : 0, sm = su >> 1, sn = su & 1;
+            if (j == 0 && qph + 2 < nph) issue_weights(cur, qph + 2, (qdy + 2) % 3);
+            if (sk == 1 && drip) {
+                if (j == 0) slot_a(sealed, prv, ec_prev, sm, sn);
+                else if (j == 1) slot_r_act(sealed, ec_prev, sm, sn, 0);
+                else slot_r_store(sealed, prv, sm, sn, 0);
             }
+            if (sk == 2) {
+                if (j == 0) { if (drip) slot_r_act(sealed, ec_prev, sm, sn, 1); }
+                else if (j == 1) {
+                    if (drip) {
+                        slot_r_store(sealed, prv, sm, sn, 1);
+                        if (su == 3) zero_border(prv);
+                    }
+                } else slot_e(sealed, nxt, has_next, sm, sn);      // the residual row of the block's next item into the unit just stored from
+            }
+            if (qdy == 0 && kq + 1 < P.NK) issue_input(cur, ioff, kq + 1, (kq + 1) & 1, 2 * j, j == 2 ? IS::PW : 2 * j + 2);
+            if (j == 0 && qdy == 2 && can_be_last && kq + 1 == P.NK && has_next) {      // (can_be_last: second K-step of a plain trip, compile time)
+                // last phase of the item: ring slots 0 / 1 and input stage 0 are out of use -> the next item's first operands
+                // (its lane offsets are formed here, not at the item top: 5 registers less across the K loop)
+                make_ioff(nxt, ioff);
+                issue_input(nxt, ioff, 0, 0);
+                issue_weights(nxt, 0, 0);
+                issue_weights(nxt, 1, 1);
+                issue_consts(nxt, par ^ 1);
+            }
+        };
+        // the wait in front of a phase's barrier.  In flight, oldest first: [slot traffic of phase ph-2] chunk ph+1 (requested behind
+        // the previous barrier), then EITHER the slot traffic of phase ph-1 (a lower bound N of its memory instructions is known, see
+        // the file header) OR -- at dy = 1 -- the 5 input pieces of K-step k+1: those youngest ones may stay in flight another phase.
+        auto phase_wait = [&](int psp, int dy, int k) {          // psp: slot-trip phase of the PREVIOUS phase, or -1
+            const int pk = psp >= 0 ? slot_kind(psp) : 0;
+            bool counted = (dbg & 32) != 0;                      // (probing: no wait at all)
+            if (pk != 0 && dbg == 0) {                           // (the other probing switches change what a slot issues: plain vmcnt(0) then)
+                const bool yok = drip && prv.y0 + wave * D_NROW + (slot_unit(psp) & 1) < P.H;      // wave-uniform: did the slot issue its stores
+                const bool big = pk == 1 ? (yok && P.y32 != nullptr) : (res_on && has_next);       // >= 16 of them
+                if (big) { MDT_VMCNT(15); counted = true; }
+                else if (yok && P.yrec != nullptr) { MDT_VMCNT(2); counted = true; }
+            }
+            if (!counted) {
+                if (dy == 1 && k + 1 < P.NK) MDT_VMCNT(5);
+                else MDT_VMCNT(0);
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        // one step = [waves 4-7: the phase's barrier] fragments of the next step out of LDS, 12 MFMAs, [waves 0-3: the phase's barrier], piece dx
+        //   t: step of the unrolled trip, T: its length, kb: first K-step of the trip, SLOTS: the slot trip (the item's K-steps 0 .. 3)
+        auto step = [&](int t, int T, int kb, bool SLOTS, bool more) {
+            const int kk = t / 9, dy = (t / 3) % 3, dx = t % 3, pl_ = t / 3;
+            const int k = kb + kk;
+            const int ws = t & 1;
+            // the phase before this one as a slot-trip phase: of this trip, or (first phase of the first plain trip: kb == D_TK, a run-time
+            // test) the slot trip's last one; the item's very first phase has none (the item top waited for everything)
+            auto wait_here = [&]() {
+                if (!SLOTS && pl_ == 0) {
+                    if (kb == D_TK) phase_wait(3 * D_TK - 1, dy, k);
+                    else phase_wait(-1, dy, k);
+                } else {
+                    phase_wait(SLOTS ? pl_ - 1 : -1, dy, k);
+                }
+            };
+            if (dx == 0 && wave >= 4) wait_here();
+            MDT_PIN();
+            if (t < T - 1) {
+                const int t1 = t + 1;
+                load_fw(ws ^ 1, (t1 / 3) % 3, t1 % 3);
+                load_fx(ws ^ 1, (t1 / 9) & 1, (t1 / 3) % 3, t1 % 3);
+            } else if (more) {
+                load_fw(ws ^ 1, 0, 0);
+                load_fx(ws ^ 1, 0, 0, 0);
+            }
+            MDT_PIN();
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int n = 0; n < D_NROW; ++n)
+#pragma unroll
+                    for (int m = 0; m < D_MT; ++m)
+                        acc[m][n][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ws][m][term == 0 ? 1 : 0], fx[ws][n][term == 1 ? 1 : 0],
+                                                                               acc[m][n][0], 0, 0, 0);   // w_lo x_hi, w_hi x_lo, w_hi x_hi
+            MDT_PIN();
+            if (dx == 0 && wave < 4) wait_here();
+            piece(SLOTS ? pl_ : -1, dy, k, dx, !SLOTS && kk == 1);
+        };
+
+        // the slot trip: K-steps 0 .. 3 of the item, the previous item's epilogue and the next item's residual rows in its slots
+#pragma unroll
+        for (int t = 0; t < 9 * D_TK; ++t) step(t, 9 * D_TK, 0, true, true);
+        // the rest of the K loop in trips of two K-steps (its own unrolled body, see the file header)
+        for (int k2 = D_TK; k2 < P.NK; k2 += 2) {
+#pragma unroll
+            for (int t = 0; t < 18; ++t) step(t, 18, k2, false, k2 + 2 < P.NK);
         }
 
         prv = cur;
@@ -439,8 +483,6 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_recd(const ConvRParams P) {
         work = work_n;
         cur = nxt;
         par ^= 1;
-#pragma unroll
-        for (int i = 0; i < IS::PW; ++i) ioff[i] = ioff_n[i];
     }
 
     // the block's last item: nothing left to hide under -- its epilogue in one piece
@@ -451,8 +493,10 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_recd(const ConvRParams P) {
 #pragma unroll
             for (int n = 0; n < D_NROW; ++n) {
                 slot_a(acc, prv, ec_last, m, n);
-                slot_r(acc, prv, ec_last, m, n, 0);
-                slot_r(acc, prv, ec_last, m, n, 1);
+                slot_r_act(acc, ec_last, m, n, 0);
+                slot_r_store(acc, prv, m, n, 0);
+                slot_r_act(acc, ec_last, m, n, 1);
+                slot_r_store(acc, prv, m, n, 1);
             }
         zero_border(prv);
     }
@@ -463,7 +507,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_recd(const ConvRParams P) {
 namespace mdt {
 
 // cin % 64 == 0 (whole 4-K-step trips), 128-cout packed blocks; H, W: output = input size
-bool conv_recd_supported(int cout, int cin) { return cin % 64 == 0 && cin >= 128 && cout % 128 == 0; }
+bool conv_recd_supported(int cout, int cin) { return cin % 32 == 0 && cin >= 128 && cout % 128 == 0; }
 
 int conv_recd_launch(ConvRParams P, int B, hipStream_t s, int cus) {
     P.PX = (P.W + 31) / 32;
