@@ -71,6 +71,10 @@ def parse():
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the per-stage split and the HIP-event roofline pass (PMC runs)")
     ap.add_argument("--no-oracle-pass", action="store_true", help="skip parity.rel_err_vs_oracle (assembled cfg3 decode vs the oracle on the GPU, untimed)")
     ap.add_argument("--no-stress-pass", action="store_true", help="skip parity.rel_err_vs_oracle_stress (cfg3 decode of the trained-like 'stress' decoder vs the oracle on the GPU, untimed)")
+    ap.add_argument("--encode", action="store_true", help="the ENCODE direction instead (SURVEY section 8 f1): one line for the tiled VAE encode of an "
+                    "8192x8192 image at encoder tile 3072 -- time, dominant kernel + roofline fraction, parity of one tile vs the oracle")
+    ap.add_argument("--encode-side", type=int, default=8192)
+    ap.add_argument("--encode-tile", type=int, default=3072)
     ap.add_argument("--cpu-vae-latent", type=int, default=88, help="width of the 64-row latent of the CPU VAE sample")
     ap.add_argument("--debug-single-device", action="store_true",
                     help="functional check of the N > 1 flow on ONE GPU: every rank uses cuda:0 and gloo (host-staged) instead "
@@ -110,6 +114,104 @@ class Profile:
             a[1] += work
             a[2] += s.elapsed_time(e) * 1e-3
         return agg
+
+
+def run_encode(args, E, pl, ld, dev):
+    """`--encode`: the tiled VAE ENCODE (upstream scripts/tilevae.py:155-171 Downsample tasks, :492-496 encoder estimator, :507-656 the tile
+    sweep with is_decoder=False) of one image on one GPU: W untimed + K timed encodes, per-kernel HIP-event roofline of one extra encode,
+    and -- untimed -- ONE tile of the timed image against the oracle (oracle/vae_oracle.py via oracle/gpu_reference.py, fast mode:
+    with every GroupNorm frozen a tile depends on no other tile)."""
+    import builtins
+    side, tile = args.encode_side, args.encode_tile
+    enc = ld.make_encoder(0).to(dev)
+    enc.original_forward = enc.forward
+    hook = pl.tilevae.VAEHook(enc, tile, is_decoder=False, fast_decoder=False, fast_encoder=not args.slow_vae, color_fix=False)
+    x = torch.randn(1, 3, side, side, generator=torch.Generator().manual_seed(1)).to(dev)
+    _print = builtins.print
+
+    def quiet(fn):
+        builtins.print = lambda *a, **k: None
+        try:
+            return fn()
+        finally:
+            builtins.print = _print
+
+    for _ in range(max(1, args.warmup)):
+        quiet(lambda: hook(x))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = quiet(lambda: hook(x))
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / args.steps
+    lat = (side // 8) * (side // 8)
+    # per-kernel roofline of one more encode (HIP events around every conv / attention launch, same stream)
+    prof = Profile()
+    orig_call, orig_down, orig_attn, orig_rec = E.PackedConv.__call__, E.PackedConv.down2, E.vae_attn, E.PackedConv.call_rec
+    bfx = E.get_precision() == E.PRECISION_BF16X3
+
+    def timed_rec(self, xx, residual=None, upsample2x=False, want_f32=True, want_rec=False, rec_coef=None, window=None, family=0):
+        B, cin, H, W = xx.shape
+        tag = "k_conv3x3_rec<2, 2, 4> + k_conv3x3_rec2<2, 2, 4>" if self.cout % 128 == 0 else "k_conv3x3_rec<1, 1, 2>"
+        return prof.wrap(tag, 2.0 * B * H * W * self.cout * cin * 9, lambda: orig_rec(self, xx, residual, upsample2x, want_f32, want_rec, rec_coef, window, family))
+
+    def timed_call(self, xx, residual=None, upsample2x=False, token_major=False, exact=False, pre_gn=None):
+        B, cin, H, W = xx.shape
+        flops = 2.0 * B * H * W * self.cout * cin * self.ksize * self.ksize
+        bf = bfx and not exact and not token_major and cin % 16 == 0
+        tag = ("k_conv1x1_stream<*> / k_conv1x1_bf16x3<*>" if (bf and cin % 32 == 0) else "k_conv<1,*> (exact fp32 MFMA)") if self.ksize == 1 else \
+              ("k_conv3x3_bf16x3<*> (fp32 hand-over)" if bf else "k_conv<3,*> (exact fp32 MFMA)")
+        return prof.wrap(tag, flops, lambda: orig_call(self, xx, residual, upsample2x, token_major, exact, pre_gn))
+
+    def timed_down(self, xx):
+        B, cin, H, W = xx.shape
+        ho, wo = (H - 2) // 2 + 1, (W - 2) // 2 + 1
+        return prof.wrap("k_conv3x3_bf16x3<*, false, 2> (Downsample)" if bfx else "k_conv<3,*,2> (exact fp32 MFMA)", 2.0 * B * ho * wo * self.cout * cin * 9,
+                         lambda: orig_down(self, xx))
+
+    def timed_attn(q, k, v, scale, exact=False, v_channel_major=False):
+        B, Cc, T = q.shape
+        return prof.wrap("k_attn_bf16x3<512>" if bfx and not exact else "k_attn<*> (exact fp32 MFMA)", 4.0 * B * T * T * Cc,
+                         lambda: orig_attn(q, k, v, scale, exact, v_channel_major))
+
+    E.PackedConv.__call__, E.PackedConv.down2, E.vae_attn, E.PackedConv.call_rec = timed_call, timed_down, timed_attn, timed_rec
+    try:
+        quiet(lambda: hook(x))
+    finally:
+        E.PackedConv.__call__, E.PackedConv.down2, E.vae_attn, E.PackedConv.call_rec = orig_call, orig_down, orig_attn, orig_rec
+    agg = prof.summary()
+    mm = {k: v for k, v in agg.items() if k.startswith("k_")}
+    dom = max(mm, key=lambda k_: mm[k_][2])
+    n, work, secs = mm[dom]
+    peak = MFMA_BF16X3_PEAK_TFLOPS if ("bf16x3" in dom or "_rec" in dom) else MFMA_F32_PEAK_TFLOPS
+    roofline = {"kernel": dom, "bound": "mfma", "achieved": round(work / secs / 1e12, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                "frac": round(work / secs / 1e12 / peak, 4), "traffic": None, "launches": n, "avg_us": round(secs / n * 1e6, 1),
+                "share_of_encode": round(secs / (ms * 1e-3), 3),
+                "breakdown_s": {k: round(v[2], 4) for k, v in sorted(agg.items())},
+                "breakdown_tflops": {k: round(v[1] / v[2] / 1e12, 2) for k, v in sorted(mm.items())}}
+    # parity: one tile of the timed image vs the oracle on this GPU (fast mode only)
+    parity = None
+    if not args.no_oracle_pass and not args.slow_vae:
+        from oracle import gpu_reference as gr, vae_oracle as vo
+        ins, outs = vo.split_tiles(side, side, tile, False)
+        pick = len(ins) // 2 if len(ins) > 2 else len(ins) - 1
+        t0 = time.perf_counter()
+        (ob, crop), = quiet(lambda: gr.tiled_forward_gpu(enc, x, tile, True, is_decoder=False, only_tiles=[pick]))
+        t_or = time.perf_counter() - t0
+        mine = y.float()[:, :, ob[2]:ob[3], ob[0]:ob[1]]
+        den = y.float().abs().max().item()
+        d = (mine - crop.to(mine.device)).abs()
+        parity = {"rel_err_vs_oracle_tile": float(d.max().item() / den), "rms_err_vs_oracle_tile": float((d.pow(2).mean().sqrt() / den).item()), "tile": pick,
+                  "pixel_in_bbox": ins[pick], "latent_out_bbox": ob, "tolerance": 1e-3,
+                  "what": f"tile {pick} of {len(ins)} of the TIMED image: the engine's moments vs the oracle's encode of the same tile with its own estimator "
+                          f"statistics (torch fp32 on this GPU, {t_or:.0f} s); relative to the output's absolute maximum"}
+    return {"metric": "latent-px/sec tiled-VAE-encode, 8K image", "value": round(lat / (ms * 1e-3), 1), "unit": "latent-px/s", "n_gpus": 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32" if E.get_precision() == E.PRECISION_F32 else "bf16x3+f32", "data": "synthetic",
+            "config": {"workload": f"tiled VAE ENCODE of a {side}x{side} image (encoder tile {tile}, {'slow' if args.slow_vae else 'fast'} mode, SD encoder ch=128, random weights) "
+                                   f"-> {side // 8}x{side // 8} latent moments", "image": [side, side], "vae_tile": tile},
+            "roofline": roofline, "parity": parity, "cpu_baseline": None,
+            "note": "companion line of the ENCODE direction (SURVEY section 8 f1); the headline metric of BASELINE.json is the default run"}
 
 
 def main():
@@ -168,6 +270,11 @@ def main():
                 else:
                     transport = "gloo (host-staged: neither RCCL communicator came up)"
     from hostsim import ldm_decoder as ld  # the random-weight SD-shaped decoder definition (the nn.Module the hook is attached to)
+    if args.encode:
+        if world != 1:
+            raise SystemExit("--encode is a single-GPU companion line")
+        print(json.dumps(run_encode(args, E, pl, ld, dev)))
+        return
 
     L, N, C = args.latent, 2, 4
     method = E.METHOD_MD if args.method == "md" else E.METHOD_MOD
@@ -364,7 +471,7 @@ def main():
                     tag = "k_conv3x3_bf16x3<*> (fp32 hand-over)" if bf else "k_conv<3,*> (exact fp32 MFMA)"
                 return prof.wrap(tag, flops, lambda: orig_call(self, x, residual, upsample2x, token_major, exact, pre_gn))
 
-            def timed_rec(self, x, residual=None, upsample2x=False, want_f32=True, want_rec=False, rec_coef=None, window=None):
+            def timed_rec(self, x, residual=None, upsample2x=False, want_f32=True, want_rec=False, rec_coef=None, window=None, family=0):
                 # record kernels: the tag IS the kernel symbol mdtile_conv2d_rec launches (csrc/vae_conv_rec.hip, dispatch at the end)
                 B, cin, H, W = x.shape
                 if window is not None:
@@ -376,7 +483,7 @@ def main():
                 if upsample2x:
                     flops *= 4.0 / 9.0
                     tag = "k_upconv_rec"
-                return prof.wrap(tag, flops, lambda: orig_rec(self, x, residual, upsample2x, want_f32, want_rec, rec_coef, window))
+                return prof.wrap(tag, flops, lambda: orig_rec(self, x, residual, upsample2x, want_f32, want_rec, rec_coef, window, family))
 
             orig_attn = E.vae_attn
 
@@ -421,7 +528,10 @@ def main():
             ach = work / secs / 1e12
             bf16x3 = "bf16x3" in dom or "_rec" in dom
             peak = MFMA_BF16X3_PEAK_TFLOPS if bf16x3 else MFMA_F32_PEAK_TFLOPS
-            roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+            # the 128-cout record convs are two symbols behind one dispatch (csrc/vae_conv_rec.hip: one 8-wave block per CU; vae_conv_rec2.hip:
+            # two 4-wave blocks per CU on launches of few item rounds): the tag aggregates both, so the line names both and `traffic` sums both
+            symbols = {"k_conv3x3_rec<2, 2, 4>": ["k_conv3x3_rec<2, 2, 4>", "k_conv3x3_rec2<2, 2, 4>"], "k_upconv_rec": ["k_upconv_rec(", "k_upconv_rec2("]}.get(dom, [dom])
+            roofline = {"kernel": " + ".join(x.rstrip("(") for x in symbols), "kernel_symbols": symbols, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                         "frac": round(ach / peak, 4), "traffic": None, "launches": n,
                         "mfma_path": "bf16x3 (3 bf16 MFMAs per fp32-class product; peak = 2500/3 algorithmic TFLOP/s)" if bf16x3 else "fp32 MFMA",
                         "avg_us": round(secs / n * 1e6, 1), "flops_per_launch": work / n,
@@ -445,9 +555,9 @@ def main():
         for rl in (roofline, roofline_blend):
             if rl is None:
                 continue
-            needle = rl["kernel"].split("<*")[0].split(" (")[0]
-            needle = "k_blend<" if needle.startswith("k_blend") else needle
-            hit = [v for k, v in pmc.get("kernels", {}).items() if needle in k]
+            needles = rl.get("kernel_symbols") or [rl["kernel"].split("<*")[0].split(" (")[0]]
+            needles = ["k_blend<"] if needles[0].startswith("k_blend") else needles
+            hit = [v for k, v in pmc.get("kernels", {}).items() if any(nd_ in k for nd_ in needles)]
             if not hit:
                 continue
             src = os.path.relpath(pmc_path, ROOT)
@@ -462,6 +572,8 @@ def main():
             if ck:
                 rl["clock_GHz_measured"] = round(sum(h["clock_GHz"] * h["dispatches"] for h in ck) / max(1, sum(h["dispatches"] for h in ck)), 3)
                 rl["clock_source"] = "GRBM_GUI_ACTIVE / 8 XCDs / kernel duration in the FETCH_SIZE pass; `peak` is quoted at 2.4 GHz"
+                if rl.get("bound") == "mfma":
+                    rl["frac_at_clock"] = round(rl["achieved"] / (rl["peak"] * rl["clock_GHz_measured"] / 2.4), 4)      # against the matrix-core peak at the clock the die granted
 
     # ------------------------------------------------------------------ whole-tile companion: the same step with the live-window narrowing OFF
     # (every padded tile decoded whole, as upstream does; untimed region of the headline, its own clock).  The two assembled images must be
