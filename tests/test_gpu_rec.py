@@ -185,7 +185,7 @@ def test_upconv_window_equals_the_same_pixels_of_the_whole_image_call(plugin, cu
     x = torch.randn(B, cin, Hin, Win).to(cuda)
     coef = _coef(B, cout, 5).to(cuda)
     xr = E.rec_from_f32(x)
-    y_full, r_full = pc.call_rec(xr, upsample2x=True, want_f32=True, want_rec=True, rec_coef=coef, family=blocks)
+    y_full, r_full = pc.call_rec(xr, upsample2x=True, want_f32=True, want_rec=True, rec_coef=coef)
     y0, x0, h, w = win
     y_win, r_win = pc.call_rec(xr, upsample2x=True, want_f32=True, want_rec=True, rec_coef=coef, window=win)
     assert y_win.shape == (B, cout, 2 * h, 2 * w) and r_win.shape == (B, cout, 2 * h, 2 * w)
@@ -376,7 +376,7 @@ def test_upconv_windows_under_both_kernel_families(plugin, cuda, blocks):
     x = torch.randn(B, 256, Hin, Win).to(cuda)
     xr = E.rec_from_f32(x)
     coef = _coef(B, 128, 3).to(cuda)
-    y_full, r_full = pc.call_rec(xr, upsample2x=True, want_f32=True, want_rec=True, rec_coef=coef)
+    y_full, r_full = pc.call_rec(xr, upsample2x=True, want_f32=True, want_rec=True, rec_coef=coef, family=blocks)
     y0s, x0s = [0, 15, 6, 11], [19, 0, 7, 13]
     y_win, r_win = pc.call_rec(xr, upsample2x=True, want_f32=True, want_rec=True, rec_coef=coef, window=(y0s, x0s, h, w), family=blocks)
     rf, rw = r_full.records(), r_win.records()
