@@ -79,6 +79,15 @@ __device__ __forceinline__ void dma16(const char* base, unsigned voff, const u32
                  : "memory");
 }
 
+// the same with the LDS destination given as a byte address (per-wave constant + compile-time offset: one s_add, no pointer arithmetic)
+__device__ __forceinline__ void dma16(const char* base, unsigned voff, const u32x4*, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(base), "s"(lds_byte_addr)
+                 : "memory");
+}
+
 __device__ __forceinline__ float silu_f(float t) { return t * __builtin_amdgcn_rcpf(1.0f + __expf(-t)); }
 
 // ---- shared epilogue: one 32-cout tile of a wave (NROW pixel rows x NPX pixels per lane) -> + bias (+ residual) -> fp32 NCHW

@@ -124,31 +124,71 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_recd(const ConvRParams P) {
             ioff[i] = (unsigned)(((size_t)g * plane + (size_t)pr * Wp + pc) * 16);
         }
     };
-    auto issue_input = [&](const DItem& it, const unsigned (&ioff)[IS::PW], int k, int stage, int i0 = 0, int i1 = IS::PW) {
-        if (dbg & 64) return;
+    // ---- operand stream addresses.  A DMA piece costs the wave ~100 cycles of issue as it is (probes/conv_drip_ab.py --dbg 97: the K loop
+    // without its 88 pieces per item is 10 % faster); hipcc's address arithmetic per piece -- a 64-bit multiply by the plane stride, SGPR
+    // spill reloads -- made it 18 instructions.  The sources are therefore RUNNING pointers (SGPR pairs advanced by additions only, opaque
+    // to the optimiser so that they are never re-derived from k), the per-wave parts sit in lane offsets / per-wave LDS addresses:
+    //   input : three pointers (pieces of the hi half | piece 2, whose half depends on the wave | pieces of the lo half), + 2 planes per K-step
+    //   chunks: one pointer, + one packed chunk (24 KB) per phase; the wave's piece offset inside the chunk is part of the lane offset
+    struct P64 {      // a 64-bit address as two scalar registers (hipcc moves a 64-bit value it ADDS to into vector registers: no s_add_u64 on gfx9)
+        unsigned lo, hi;
+    };
+    auto p64 = [](const void* q) {
+        const size_t v = reinterpret_cast<size_t>(q);
+        P64 r;
+        r.lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+        r.hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+        asm volatile("" : "+s"(r.lo), "+s"(r.hi));
+        return r;
+    };
+    auto add64 = [](P64& a, const P64& k) { asm volatile("s_add_u32 %0, %0, %2\n\ts_addc_u32 %1, %1, %3" : "+s"(a.lo), "+s"(a.hi) : "s"(k.lo), "s"(k.hi) : "scc"); };
+    auto ptr_of = [](const P64& a) { return reinterpret_cast<const char*>(((size_t)a.hi << 32) | a.lo); };
+    auto opaque = [&](const char* q) { return ptr_of(p64(q)); };
+    auto lds_addr = [](const u32x4* q) { return (unsigned)(__UINTPTR_TYPE__)(const __attribute__((address_space(3))) u32x4*)q; };
+    const size_t hloff = (size_t)Pn * plane * 16;
+    const P64 kstride = p64(reinterpret_cast<const void*>((size_t)2 * plane * 16));
+    const bool mid_lo = (wave + 16) / IS::HALF_DMA != 0;      // piece 2 = DMA wave + 16: record half (wave + 16) / 20
+    P64 x_hi = {0u, 0u}, x_mid = {0u, 0u}, x_lo = {0u, 0u};      // (named by record half: hi = hl 0)
+    auto input_at = [&](const DItem& it) {      // K-step 0 of an item
         const char* xb = reinterpret_cast<const char*>(P.x + (size_t)it.b * 2 * Pn * plane);
+        x_hi = p64(xb);
+        x_lo = p64(xb + hloff);
+        x_mid = p64(mid_lo ? xb + hloff : xb);
+    };
+    auto input_next = [&]() {
+        add64(x_hi, kstride);
+        add64(x_lo, kstride);
+        add64(x_mid, kstride);
+    };
+    const unsigned in_lds_w = lds_addr(in_l) + (unsigned)wave * 1024u;      // + stage * PAD * 16 + i * 8192
+    auto issue_input = [&](const unsigned (&ioff)[IS::PW], int stage, int i0 = 0, int i1 = IS::PW) {      // the K-step the pointers stand at
+        if (dbg & 64) return;
 #pragma unroll
         for (int i = 0; i < IS::PW; ++i) {
             if (i < i0 || i >= i1) continue;
-            const int di = wave + 8 * i;
-            const char* base = xb + ((size_t)(di / IS::HALF_DMA) * Pn + 2 * (size_t)k) * plane * 16;   // wave-uniform
-            dma16(base, ioff[i], in_l + stage * IS::PAD + di * 64);
+            dma16(ptr_of(i < 2 ? x_hi : (i == 2 ? x_mid : x_lo)), ioff[i], reinterpret_cast<const u32x4*>(0), in_lds_w + (unsigned)(stage * IS::PAD * 16 + i * 8192));
         }
     };
     const unsigned lane16 = lane * 16;
     // chunk (k, dy) of the item's 64 couts: piece p = (hl, dx, mt) -> packed piece (hl, dx, 2 (cb & 1) + mt) of the 128-cout block cb >> 1
-    auto issue_weights = [&](const DItem& it, int ph, int ring) {
-        if (dbg & 64) return;
-        const char* wsrc = reinterpret_cast<const char*>(P.w + ((size_t)(it.cb >> 1) * P.NK * 3 + ph) * W_SRC);
-        const int half2 = (it.cb & 1) * 2;
+    P64 wptr = {0u, 0u};             // the next chunk to request
+    const P64 wstride = p64(reinterpret_cast<const void*>((size_t)W_SRC * 16));
+    unsigned wvoff[2], w_lds_w[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int p = wave + 8 * i;
-            if (p < W_DMA) {
-                const int q = p >> 1, mt = p & 1;      // q = hl * 3 + dx
-                dma16(wsrc + (size_t)((q * 4 + half2 + mt) * 64) * 16, lane16, w_l + ring * W_REC + p * 64);
-            }
+    for (int i = 0; i < 2; ++i) {
+        const int pw = wave + 8 * i;
+        wvoff[i] = lane16 + (unsigned)(((pw >> 1) * 4 + (pw & 1)) * 1024);
+        w_lds_w[i] = lds_addr(w_l) + (unsigned)pw * 1024u;      // + ring * W_REC * 16
+    }
+    auto weights_at = [&](const DItem& it) {      // chunk 0 of an item
+        wptr = p64(reinterpret_cast<const char*>(P.w + (size_t)(it.cb >> 1) * P.NK * 3 * W_SRC) + (it.cb & 1) * 2048);
+    };
+    auto issue_weights = [&](int ring) {          // the chunk the pointer stands at; then on to the next one
+        if (!(dbg & 64)) {
+            dma16(ptr_of(wptr), wvoff[0], reinterpret_cast<const u32x4*>(0), w_lds_w[0] + (unsigned)(ring * W_REC * 16));
+            if (wave < 4) dma16(ptr_of(wptr), wvoff[1], reinterpret_cast<const u32x4*>(0), w_lds_w[1] + (unsigned)(ring * W_REC * 16));
         }
+        add64(wptr, wstride);
     };
     // epilogue constants of an item's 64 couts: waves 0 / 1 / 2 fetch bias / a / s, 256 B each (lanes 0-15)
     auto issue_consts = [&](const DItem& it, int par) {
@@ -203,8 +243,26 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_recd(const ConvRParams P) {
         L.xc = (unsigned)(L.x < P.W ? L.x : 0);
         return L;
     };
+    // Output addresses of a finished item: ONE 64-bit base per tensor and item (SGPR pair, formed when the item ends) + a 32-bit lane offset
+    // that carries the m-tile, the lane's half, the pixel AND the plane walk (v_add per access).  epilogue_item steps a scalar pointer per
+    // plane instead (2 SALU per access): fine with idle matrix cores, but next to the MFMAs of the partner wave a scalar instruction is the
+    // expensive kind (profiles/r5g: 1.6 cycles of matrix pipe per SALU, 0.7 per VALU; this kernel ran 1.74 SALU per MFMA).
+    // 32-bit offsets: 64 planes x HW x 4 B and 8 planes x (H + 2) x pitch x 16 B stay below 2^32 (rec_image_ok on the host).
+    struct Bases {
+        gchar *y32, *rec_hi, *rec_lo;
+    };
+    auto opaque_g = [&](const void* q) { return (gchar*)reinterpret_cast<size_t>(opaque(reinterpret_cast<const char*>(q))); };
+    auto bases_of = [&](const DItem& it) {
+        Bases Bs;
+        Bs.y32 = opaque_g(reinterpret_cast<const char*>(P.y32) + ((size_t)it.b * P.Cout + (size_t)it.cb * 64) * HW4);
+        const char* rh = reinterpret_cast<const char*>(P.yrec) + ((size_t)it.b * 2 * PnO + (size_t)it.cb * 8) * pl16;
+        Bs.rec_hi = opaque_g(rh);
+        Bs.rec_lo = opaque_g(rh + lo_half);
+        return Bs;
+    };
+    const unsigned hw4u = (unsigned)HW4, hw4u5 = 5u * (unsigned)HW4;
     // A: + bias, fp32 stores
-    auto slot_a = [&](f32x16 (&S)[D_MT][D_NROW][1], const DItem& it, const u32x4* ec, int m, int n) {
+    auto slot_a = [&](f32x16 (&S)[D_MT][D_NROW][1], const DItem& it, const Bases& Bs, const u32x4* ec, int m, int n) {
         const Lane L = lane_of(it, n);
         if (P.bias) {
             const float4* e4 = reinterpret_cast<const float4*>(ec) + (m * 8 + L.kgo);
@@ -215,13 +273,11 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_recd(const ConvRParams P) {
             }
         }
         if (P.y32 && L.ok && !(dbg & 8)) {
-            const unsigned ro = ((4u * L.kgo) * (unsigned)HW + L.xc) * 4u + (unsigned)(L.y * P.W) * 4u;
-            char* const yb32 = reinterpret_cast<char*>(P.y32) + ((size_t)it.b * P.Cout + (size_t)(it.cb * D_MT + m) * 32) * HW4;
-            gchar* up = uniform_ptr(yb32);
+            unsigned off = (((unsigned)(m * 32) + 4u * L.kgo) * (unsigned)HW + (unsigned)(L.y * P.W) + L.xc) * 4u;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                if (q) up = uniform_ptr(up + MDT_PLANE_STEP(q) * HW4);
-                *(MDT_GLOBAL float*)(up + (size_t)ro) = S[m][n][0][q];
+                if (q) off += MDT_PLANE_STEP(q) == 1 ? hw4u : hw4u5;
+                *(MDT_GLOBAL float*)(Bs.y32 + (size_t)off) = S[m][n][0][q];
             }
         }
     };
@@ -240,19 +296,17 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_recd(const ConvRParams P) {
         }
         act8(S[m][n][0], 8 * R, aq, sq);
     };
-    auto slot_r_store = [&](f32x16 (&S)[D_MT][D_NROW][1], const DItem& it, int m, int n, int R) {
+    auto slot_r_store = [&](f32x16 (&S)[D_MT][D_NROW][1], const DItem& it, const Bases& Bs, int m, int n, int R) {
         if (!P.yrec) return;
         const Lane L = lane_of(it, n);
         if (!L.ok) return;
-        char* const yr = reinterpret_cast<char*>(P.yrec) + ((size_t)it.b * 2 * PnO + (size_t)(it.cb * D_MT + m) * 4) * pl16;
-        const unsigned rrow = (L.kgo * (unsigned)plane + (L.xc + (unsigned)REC_COL0)) * 16u + (unsigned)((L.y + 1) * Wp) * 16u;
-        gchar* const yp = uniform_ptr(yr + (size_t)(2 * R) * pl16), *const ypl = uniform_ptr(yp + lo_half);
+        // record (row y + 1, padded column x + 1) of plane (m 4 + 2 R + kg) of the item's 8
+        const size_t at = (size_t)((((unsigned)(m * 4 + 2 * R) + L.kgo) * (unsigned)plane + (unsigned)((L.y + 1) * Wp) + L.xc + (unsigned)(REC_COL0 + 1)) * 16u);
         u32x4 hi, lo;
         split8p(S[m][n][0], 8 * R, hi, lo);
-        const size_t at = (size_t)(rrow + 16u);
         if (!(dbg & 4)) {
-            *(MDT_GLOBAL u32x4*)(yp + at) = hi;
-            *(MDT_GLOBAL u32x4*)(ypl + at) = lo;
+            *(MDT_GLOBAL u32x4*)(Bs.rec_hi + at) = hi;
+            *(MDT_GLOBAL u32x4*)(Bs.rec_lo + at) = lo;
         } else {
             asm volatile("" ::"v"(hi), "v"(lo));      // (probing: the split stays, its stores go)
         }
@@ -294,28 +348,28 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_recd(const ConvRParams P) {
             }
         }
     };
-    // E: the unit's registers are stored -- the residual row of item `it` (the block's NEXT item) goes into them, or zeros
-    auto res_rows = [&](const DItem& it) {
-        ResRows<D_NROW> R;
-        R.on = true; R.b = it.b; R.mt_global0 = it.cb * D_MT;
-#pragma unroll
-        for (int n = 0; n < D_NROW; ++n) R.ys[n] = it.y0 + wave * D_NROW + n;
-        int le = lane;
-        asm volatile("" : "+v"(le));
-        R.x = it.x0 + (le & 31);
-        R.x_ok = R.x < P.W;
-        return R;
-    };
+    // E: the unit's registers are stored -- the residual row of the block's NEXT item goes into them
     // (loads only: without a residual the start values are zeroed at the item top -- a zeroing `else` here made hipcc merge the two
     // paths with v_cndmask behind a vmcnt(0) of its own, i.e. wait for the rows right where they were requested)
     const bool res_on = P.res != nullptr && !(dbg & 1) && !(dbg & 16);
-    auto slot_e = [&](f32x16 (&S)[D_MT][D_NROW][1], const DItem& it, bool on, int m, int n) {
+    auto slot_e = [&](f32x16 (&S)[D_MT][D_NROW][1], const DItem& it, gchar* resb, bool on, int m, int n) {
         if (res_on && on) {
-            const ResRows<D_NROW> R = res_rows(it);
-            if (n == 0) residual_into_acc<D_NROW, D_MT, 1>(P.res, P.Cout, HW, P.H, P.W, kg, R, m, 0, S);
-            else residual_into_acc<D_NROW, D_MT, 1>(P.res, P.Cout, HW, P.H, P.W, kg, R, m, 1, S);
+            // (clamped coordinates: unconditional loads, as residual_into_acc)
+            unsigned kgo = (unsigned)kg;
+            asm volatile("" : "+v"(kgo));
+            int le = lane;
+            asm volatile("" : "+v"(le));
+            const int x = it.x0 + (le & 31), y = it.y0 + wave * D_NROW + n;
+            const unsigned xc = (unsigned)(x < P.W ? x : 0), yc = (unsigned)(y < P.H ? y : P.H - 1);
+            unsigned off = (((unsigned)(m * 32) + 4u * kgo) * (unsigned)HW + yc * (unsigned)P.W + xc) * 4u;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                if (q) off += MDT_PLANE_STEP(q) == 1 ? hw4u : hw4u5;
+                S[m][n][0][q] = *(const MDT_GLOBAL float*)(resb + (size_t)off);
+            }
         }
     };
+    auto res_base_of = [&](const DItem& it) { return opaque_g(reinterpret_cast<const char*>(P.res) + ((size_t)it.b * P.Cout + (size_t)it.cb * 64) * HW4); };
 
     // ------------------------------------------------------------------------------------------------------------------
     DItem cur, nxt, prv;
@@ -324,13 +378,17 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_recd(const ConvRParams P) {
     prv = cur;
     unsigned ioff[IS::PW];
     make_ioff(cur, ioff);
-    issue_input(cur, ioff, 0, 0);
-    issue_weights(cur, 0, 0);
-    issue_weights(cur, 1, 1);
+    input_at(cur);
+    issue_input(ioff, 0);
+    input_next();
+    weights_at(cur);
+    issue_weights(0);
+    issue_weights(1);
     issue_consts(cur, 0);
     const int nph = P.NK * 3;
     int par = 0;                 // constants buffer of `cur`; the sealed item's is par ^ 1
     bool have_prev = false;
+    Bases pb = bases_of(cur);      // output bases of `prv`
 
     f32x16 acc[D_MT][D_NROW][1], sealed[D_MT][D_NROW][1];
     // the first item's start values go into `sealed` and change sides at the loop top like every later item's
@@ -338,7 +396,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_recd(const ConvRParams P) {
     for (int m = 0; m < D_MT; ++m)
 #pragma unroll
         for (int n = 0; n < D_NROW; ++n) {
-            slot_e(sealed, cur, true, m, n);
+            slot_e(sealed, cur, res_base_of(cur), true, m, n);
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[m][n][0][q] = 0.0f;
             if (!res_on) {
@@ -374,6 +432,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_recd(const ConvRParams P) {
         const int work_n = next_valid(work + gridDim.x, nxt);
         const bool has_next = work_n < total;
         const u32x4* const ec_prev = ec_l + (par ^ 1) * ECD_REC;
+        gchar* const resb = res_base_of(nxt);
         const bool drip = have_prev && !(dbg & 1);
 
         // the requests of a phase in three pieces, one behind each of its MFMA blocks (see the file header)
@@ -382,29 +441,35 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_recd(const ConvRParams P) {
         auto piece = [&](int sp, int qdy, int kq, int j, bool can_be_last) {      // sp: phase of the slot trip (0 .. 11) or -1, tap row, K-step, piece j
             const int qph = kq * 3 + qdy;
             const int sk = sp >= 0 ? slot_kind(sp) : 0, su = sk ? slot_unit(sp) : 0, sm = su >> 1, sn = su & 1;
-            if (j == 0 && qph + 2 < nph) issue_weights(cur, qph + 2, (qdy + 2) % 3);
+            if (j == 0 && qph + 2 < nph) issue_weights((qdy + 2) % 3);
             if (sk == 1 && drip) {
-                if (j == 0) slot_a(sealed, prv, ec_prev, sm, sn);
+                if (j == 0) slot_a(sealed, prv, pb, ec_prev, sm, sn);
                 else if (j == 1) slot_r_act(sealed, ec_prev, sm, sn, 0);
-                else slot_r_store(sealed, prv, sm, sn, 0);
+                else slot_r_store(sealed, prv, pb, sm, sn, 0);
             }
             if (sk == 2) {
                 if (j == 0) { if (drip) slot_r_act(sealed, ec_prev, sm, sn, 1); }
                 else if (j == 1) {
                     if (drip) {
-                        slot_r_store(sealed, prv, sm, sn, 1);
+                        slot_r_store(sealed, prv, pb, sm, sn, 1);
                         if (su == 3) zero_border(prv);
                     }
-                } else slot_e(sealed, nxt, has_next, sm, sn);      // the residual row of the block's next item into the unit just stored from
+                } else slot_e(sealed, nxt, resb, has_next, sm, sn);      // the residual row of the block's next item into the unit just stored from
             }
-            if (qdy == 0 && kq + 1 < P.NK) issue_input(cur, ioff, kq + 1, (kq + 1) & 1, 2 * j, j == 2 ? IS::PW : 2 * j + 2);
+            if (qdy == 0 && kq + 1 < P.NK) {
+                issue_input(ioff, (kq + 1) & 1, 2 * j, j == 2 ? IS::PW : 2 * j + 2);
+                if (j == 2) input_next();
+            }
             if (j == 0 && qdy == 2 && can_be_last && kq + 1 == P.NK && has_next) {      // (can_be_last: second K-step of a plain trip, compile time)
                 // last phase of the item: ring slots 0 / 1 and input stage 0 are out of use -> the next item's first operands
                 // (its lane offsets are formed here, not at the item top: 5 registers less across the K loop)
                 make_ioff(nxt, ioff);
-                issue_input(nxt, ioff, 0, 0);
-                issue_weights(nxt, 0, 0);
-                issue_weights(nxt, 1, 1);
+                input_at(nxt);
+                issue_input(ioff, 0);
+                input_next();
+                weights_at(nxt);
+                issue_weights(0);
+                issue_weights(1);
                 issue_consts(nxt, par ^ 1);
             }
         };
@@ -446,13 +511,18 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_recd(const ConvRParams P) {
             };
             if (dx == 0 && wave >= 4) wait_here();
             MDT_PIN();
+            // (one explicit LDS wait per block: everything but the 8 fragment reads just issued -- hipcc otherwise stages four of its own, lgkmcnt(11) .. (8))
             if (t < T - 1) {
                 const int t1 = t + 1;
                 load_fw(ws ^ 1, (t1 / 3) % 3, t1 % 3);
                 load_fx(ws ^ 1, (t1 / 9) & 1, (t1 / 3) % 3, t1 % 3);
+                __builtin_amdgcn_s_waitcnt(0xC87F);      // lgkmcnt(8)
             } else if (more) {
                 load_fw(ws ^ 1, 0, 0);
                 load_fx(ws ^ 1, 0, 0, 0);
+                __builtin_amdgcn_s_waitcnt(0xC87F);
+            } else {
+                __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0)
             }
             MDT_PIN();
 #pragma unroll
@@ -478,6 +548,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_recd(const ConvRParams P) {
         }
 
         prv = cur;
+        pb = bases_of(cur);
         have_prev = true;
         if (!has_next) break;
         work = work_n;
@@ -492,11 +563,11 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_recd(const ConvRParams P) {
         for (int m = 0; m < D_MT; ++m)
 #pragma unroll
             for (int n = 0; n < D_NROW; ++n) {
-                slot_a(acc, prv, ec_last, m, n);
+                slot_a(acc, prv, pb, ec_last, m, n);
                 slot_r_act(acc, ec_last, m, n, 0);
-                slot_r_store(acc, prv, m, n, 0);
+                slot_r_store(acc, prv, pb, m, n, 0);
                 slot_r_act(acc, ec_last, m, n, 1);
-                slot_r_store(acc, prv, m, n, 1);
+                slot_r_store(acc, prv, pb, m, n, 1);
             }
         zero_border(prv);
     }

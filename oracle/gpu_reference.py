@@ -6,7 +6,7 @@ independent of libmdtile.so, for the tile sizes the CPU oracle cannot finish in 
 
 Two adaptations, both exact:
   * big stride-1 'same' convs are evaluated in horizontal bands with a one-row halo (torch's im2col index is 32-bit; rows of a conv
-    are independent);
+    are independent); likewise the encoder's stride-2 Downsample conv, in bands of output rows;
   * the T x T attention matrix of tile_utils/attn.py:49-72 is formed for `chunk` queries at a time (23.9 GB otherwise; the softmax
     is row-wise).
 MIOpen is switched off while the reference runs: a fresh box has no kernel cache and every new conv shape would JIT for tens of seconds.
@@ -27,6 +27,17 @@ def banded_conv2d(x, w, b=None, stride=1, padding=0, dilation=1, groups=1):
     k = w.shape[-1]
     same = stride in (1, (1, 1)) and padding in (k // 2, (k // 2, k // 2)) and dilation in (1, (1, 1)) and groups == 1
     cols = x.shape[1] * k * k * x.shape[2] * x.shape[3]
+    down = stride in (2, (2, 2)) and padding in (0, (0, 0)) and dilation in (1, (1, 1)) and groups == 1 and k == 3
+    if x.is_cuda and down and cols // 4 > 2 ** 29:
+        # ldm Downsample (encoder, scripts/tilevae.py:155-171): 3x3 stride 2 over an explicitly padded input -- output row r reads input rows
+        # 2r .. 2r+2, so bands of output rows are independent too (same 32-bit im2col limit)
+        Ho = (x.shape[2] - 3) // 2 + 1
+        band = max(8, (2 ** 28) // (x.shape[1] * k * k * ((x.shape[3] - 3) // 2 + 1)))
+        outs = []
+        for y0 in range(0, Ho, band):
+            y1 = min(Ho, y0 + band)
+            outs.append(_orig_conv2d(x[:, :, 2 * y0:2 * (y1 - 1) + 3], w, b, 2, 0, 1, 1))
+        return torch.cat(outs, dim=2)
     if not (x.is_cuda and same and cols > 2 ** 29):
         return _orig_conv2d(x, w, b, stride, padding, dilation, groups)
     H, h = x.shape[2], k // 2
