@@ -28,20 +28,23 @@ def banded_conv2d(x, w, b=None, stride=1, padding=0, dilation=1, groups=1):
     same = stride in (1, (1, 1)) and padding in (k // 2, (k // 2, k // 2)) and dilation in (1, (1, 1)) and groups == 1
     cols = x.shape[1] * k * k * x.shape[2] * x.shape[3]
     down = stride in (2, (2, 2)) and padding in (0, (0, 0)) and dilation in (1, (1, 1)) and groups == 1 and k == 3
-    if x.is_cuda and down and cols // 4 > 2 ** 29:
+    if x.is_cuda and down and (cols // 4 > 2 ** 29 or w.shape[0] * x.shape[2] * x.shape[3] // 4 > 2 ** 29):
         # ldm Downsample (encoder, scripts/tilevae.py:155-171): 3x3 stride 2 over an explicitly padded input -- output row r reads input rows
         # 2r .. 2r+2, so bands of output rows are independent too (same 32-bit im2col limit)
         Ho = (x.shape[2] - 3) // 2 + 1
-        band = max(8, (2 ** 28) // (x.shape[1] * k * k * ((x.shape[3] - 3) // 2 + 1)))
+        band = max(8, min((2 ** 28) // (x.shape[1] * k * k * ((x.shape[3] - 3) // 2 + 1)), (2 ** 28) // (w.shape[0] * ((x.shape[3] - 3) // 2 + 1))))
         outs = []
         for y0 in range(0, Ho, band):
             y1 = min(Ho, y0 + band)
             outs.append(_orig_conv2d(x[:, :, 2 * y0:2 * (y1 - 1) + 3], w, b, 2, 0, 1, 1))
         return torch.cat(outs, dim=2)
-    if not (x.is_cuda and same and cols > 2 ** 29):
+    # (the OUTPUT counts too: torch's native conv writes rows past 2^32 bytes of its result to the wrong place -- conv_in 3 -> 128 on a
+    # 3072 x 3072 encoder image has a small im2col buffer and a 4.8 GB result; probes/enc_debug.py, profiles/r5k)
+    outn = w.shape[0] * x.shape[2] * x.shape[3]
+    if not (x.is_cuda and same and (cols > 2 ** 29 or outn > 2 ** 29)):
         return _orig_conv2d(x, w, b, stride, padding, dilation, groups)
     H, h = x.shape[2], k // 2
-    band = max(8, (2 ** 28) // (x.shape[1] * k * k * x.shape[3]))
+    band = max(8, min((2 ** 28) // (x.shape[1] * k * k * x.shape[3]), (2 ** 28) // (w.shape[0] * x.shape[3])))
     outs = []
     for y0 in range(0, H, band):
         y1 = min(H, y0 + band)

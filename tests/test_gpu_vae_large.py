@@ -219,3 +219,22 @@ def test_interior_tile_padded_on_four_sides_vs_oracle_on_gpu(plugin, cuda, live)
     err_centre = (out[:, :, ob[2]:ob[3], ob[0]:ob[1]] - ref[:, :, ob[2]:ob[3], ob[0]:ob[1]]).abs().max().item() / den
     print(f"3 x 3 tiles at decoder tile 64 (live windows {live}): assembled rel err {err:.2e}, centre tile {err_centre:.2e}")
     assert err < 2e-4 and err_centre < 2e-4, f"live={live}: assembled {err}, centre tile {err_centre}"
+
+
+def test_encode_at_upstream_recommended_tile_vs_oracle_on_gpu(plugin, cuda):
+    """ENCODE direction at upstream's recommended encoder tile for > 16 GB (3072, scripts/tilevae.py:79-87): a 6144 x 6144 image -> 2 x 2 tiles of
+    3104^2 px (T = 150 544-token attention, 128 -> 128 convs on 3104^2 planes, three stride-2 Downsample convs), fast mode; one tile of the
+    engine's moments against the oracle's encode of the same tile on the GPU.  (At this size torch's native conv writes the rows past 2^32
+    bytes of its RESULT to the wrong place -- conv_in's 4.8 GB output; oracle/gpu_reference.py bands by output size too, probes/enc_oracle_walk.py.)"""
+    enc = ld.make_encoder(0).to(cuda)
+    enc.original_forward = enc.forward
+    x = torch.randn(1, 3, 6144, 6144, generator=torch.Generator().manual_seed(1)).to(cuda)
+    hook = plugin.tilevae.VAEHook(enc, 3072, is_decoder=False, fast_decoder=False, fast_encoder=True, color_fix=False)
+    y = hook(x).float()
+    assert y.shape == (1, 8, 768, 768)
+    ins, outs = vo.split_tiles(6144, 6144, 3072, False)
+    assert len(ins) == 4
+    (ob, crop), = gr.tiled_forward_gpu(enc, x, 3072, True, is_decoder=False, only_tiles=[2])
+    err = (y[:, :, ob[2]:ob[3], ob[0]:ob[1]] - crop).abs().max().item() / y.abs().max().item()
+    print(f"encode 6144^2 at encoder tile 3072, tile 2 vs the oracle on the GPU: {err:.2e}")
+    assert err < 2e-4
