@@ -150,18 +150,18 @@ def run_encode(args, E, pl, ld, dev):
     orig_call, orig_down, orig_attn, orig_rec = E.PackedConv.__call__, E.PackedConv.down2, E.vae_attn, E.PackedConv.call_rec
     bfx = E.get_precision() == E.PRECISION_BF16X3
 
-    def timed_rec(self, xx, residual=None, upsample2x=False, want_f32=True, want_rec=False, rec_coef=None, window=None, family=0):
+    def timed_rec(self, xx, residual=None, upsample2x=False, want_f32=True, want_rec=False, rec_coef=None, window=None, family=0, **kw):
         B, cin, H, W = xx.shape
         tag = "k_conv3x3_rec<2, 2, 4> + k_conv3x3_rec2<2, 2, 4>" if self.cout % 128 == 0 else "k_conv3x3_rec<1, 1, 2>"
-        return prof.wrap(tag, 2.0 * B * H * W * self.cout * cin * 9, lambda: orig_rec(self, xx, residual, upsample2x, want_f32, want_rec, rec_coef, window, family))
+        return prof.wrap(tag, 2.0 * B * H * W * self.cout * cin * 9, lambda: orig_rec(self, xx, residual, upsample2x, want_f32, want_rec, rec_coef, window, family, **kw))
 
-    def timed_call(self, xx, residual=None, upsample2x=False, token_major=False, exact=False, pre_gn=None):
+    def timed_call(self, xx, residual=None, upsample2x=False, token_major=False, exact=False, pre_gn=None, **kw):
         B, cin, H, W = xx.shape
         flops = 2.0 * B * H * W * self.cout * cin * self.ksize * self.ksize
         bf = bfx and not exact and not token_major and cin % 16 == 0
         tag = ("k_conv1x1_stream<*> / k_conv1x1_bf16x3<*>" if (bf and cin % 32 == 0) else "k_conv<1,*> (exact fp32 MFMA)") if self.ksize == 1 else \
               ("k_conv3x3_bf16x3<*> (fp32 hand-over)" if bf else "k_conv<3,*> (exact fp32 MFMA)")
-        return prof.wrap(tag, flops, lambda: orig_call(self, xx, residual, upsample2x, token_major, exact, pre_gn))
+        return prof.wrap(tag, flops, lambda: orig_call(self, xx, residual, upsample2x, token_major, exact, pre_gn, **kw))
 
     def timed_down(self, xx):
         B, cin, H, W = xx.shape
@@ -455,7 +455,7 @@ def main():
             orig_rec = E.PackedConv.call_rec
             subpixel = E.get_precision() == E.PRECISION_BF16X3
 
-            def timed_call(self, x, residual=None, upsample2x=False, token_major=False, exact=False, pre_gn=None):
+            def timed_call(self, x, residual=None, upsample2x=False, token_major=False, exact=False, pre_gn=None, **kw):
                 # the fp32 hand-over kernels (estimator pass, 1x1 convs, conv_in): tagged by kernel family
                 B, cin, H, W = x.shape
                 if upsample2x:
@@ -469,9 +469,9 @@ def main():
                     tag = "k_upconv_bf16x3<*> (fp32 hand-over)"
                 else:
                     tag = "k_conv3x3_bf16x3<*> (fp32 hand-over)" if bf else "k_conv<3,*> (exact fp32 MFMA)"
-                return prof.wrap(tag, flops, lambda: orig_call(self, x, residual, upsample2x, token_major, exact, pre_gn))
+                return prof.wrap(tag, flops, lambda: orig_call(self, x, residual, upsample2x, token_major, exact, pre_gn, **kw))
 
-            def timed_rec(self, x, residual=None, upsample2x=False, want_f32=True, want_rec=False, rec_coef=None, window=None, family=0):
+            def timed_rec(self, x, residual=None, upsample2x=False, want_f32=True, want_rec=False, rec_coef=None, window=None, family=0, **kw):
                 # record kernels: the tag IS the kernel symbol mdtile_conv2d_rec launches (csrc/vae_conv_rec.hip, dispatch at the end)
                 B, cin, H, W = x.shape
                 if window is not None:
@@ -483,7 +483,7 @@ def main():
                 if upsample2x:
                     flops *= 4.0 / 9.0
                     tag = "k_upconv_rec"
-                return prof.wrap(tag, flops, lambda: orig_rec(self, x, residual, upsample2x, want_f32, want_rec, rec_coef, window, family))
+                return prof.wrap(tag, flops, lambda: orig_rec(self, x, residual, upsample2x, want_f32, want_rec, rec_coef, window, family, **kw))
 
             orig_attn = E.vae_attn
 

@@ -272,6 +272,21 @@ int mdtile_conv2d_gn_supported(int cout, int cin, int ksize, int flags, int out_
 int mdtile_conv2d_gn(const float* d_x, const float* d_coef, const float* d_w_packed, const float* d_bias, const float* d_residual,
                      float* d_y, int B, int cin, int cout, int H, int W, int ksize, int flags, mdtile_stream_t stream);
 
+/* Slow mode (round 5): the conv whose output is the input of a POOLED GroupNorm leaves that output's statistics itself -- what
+ * GroupNormParam.add_tile asks of get_var_mean (tilevae.py:207-215, 300-307) without the pass that re-reads the activation.  The kernels'
+ * epilogues write (sum, sum of squares) per block and 4-cout quad (fp32 inside a lane's <= 16 values, fp64 from there on); two small kernels combine them in a fixed order
+ * (deterministic, no atomics) into d_mean / d_var [B * groups] (biased variance, as mdtile_gn_stats).  d_y is bit-identical to the call
+ * without statistics.  d_ws: mdtile_conv_stats_ws_size(B, cout, H, W, groups) bytes (H, W = OUTPUT size), 16-byte aligned.
+ *   mdtile_conv2d_gn_stats(_supported)  : mdtile_conv2d_gn + statistics (128-cout blocks: cout % 128 == 0; (cout / groups) % 4 == 0)
+ *   mdtile_conv2d_rec_stats(_supported) : mdtile_conv2d_rec (fp32 output only; MDTILE_CONV_UPSAMPLE2X allowed) + statistics, declared below.
+ *                                         Launches of only a few item rounds keep the kernel family mdtile_conv2d_rec would choose and
+ *                                         run the statistics pass inside the call (same results contract, one entry point). */
+size_t mdtile_conv_stats_ws_size(int B, int cout, int H, int W, int groups);
+int mdtile_conv2d_gn_stats_supported(int cout, int cin, int ksize, int flags, int groups);
+int mdtile_conv2d_gn_stats(const float* d_x, const float* d_coef, const float* d_w_packed, const float* d_bias, const float* d_residual,
+                           float* d_y, int B, int cin, int cout, int H, int W, int ksize, int flags, int groups, float* d_mean, float* d_var,
+                           void* d_ws, mdtile_stream_t stream);
+
 /* Record-image conv path (fast mode: every GroupNorm's statistics are frozen before the tiles run, tilevae.py:464-505, 542-563).
  * A "record image" of an activation [B, C, H, W] (C % 32 == 0) is its split-bf16 form in MFMA fragment order with a
  * 1-pixel zero border:  rec[b][hl][C/8][H+2][pitch] x 16 bytes, hl = 0: bf16(x), hl = 1: bf16(x - hi); plane p = 2*kstep + kg
@@ -300,6 +315,10 @@ int mdtile_conv2d_rec_supported(int cout, int cin, int ksize, int flags);
 int mdtile_conv2d_rec(const void* d_x_rec, const float* d_w_packed, const float* d_bias, const float* d_residual, float* d_y,
                       void* d_y_rec, const float* d_y_coef, int B, int cin, int cout, int H, int W, int flags,
                       mdtile_stream_t stream);
+int mdtile_conv2d_rec_stats_supported(int cout, int cin, int ksize, int flags, int groups);
+int mdtile_conv2d_rec_stats(const void* d_x_rec, const float* d_w_packed, const float* d_bias, const float* d_residual, float* d_y,
+                            int B, int cin, int cout, int H, int W, int flags, int groups, float* d_mean, float* d_var, void* d_ws,
+                            mdtile_stream_t stream);
 /* Live-window narrowing of a decoder tile (fast mode only: frozen GroupNorm statistics make every later layer local).  Upstream decodes the
  * whole padded tile and crop_valid_region (tilevae.py:248-259, applied at :630-632) throws the padding away at the end; a pixel the remaining
  * 3x3 convs cannot carry into the valid region need not be computed at all.  The narrowing happens where the resolution doubles:

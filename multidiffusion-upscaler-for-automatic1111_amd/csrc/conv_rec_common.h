@@ -40,6 +40,7 @@ struct ConvRParams {
     unsigned* cu_ctr;         // [16 XCC ids x 256 hardware CU ids] arrival counters, word = launch epoch << 8 | blocks of that launch seen on the CU; null = skew by block index
     unsigned epoch;           // this launch's epoch (24 bits, host counter per device): a counter word of another epoch restarts at 0
     unsigned* census;         // probing: [gridDim.x] hardware id of the CU each block ran on | arrival parity << 31, or null
+    double* gn_part;          // statistics kernels (k_conv3x3_rec_st / k_upconv_rec_st) only: per-wave partials of the output, see epilogue_item<.., ST>
     int dbg;                  // probing (MDTILE_REC_DBG): bit 0 = skip the epilogue (K loop only: nothing is written); bit 3 = block 0 of the
                               // one-block kernel writes s_memtime stamps per wave and item to `census` (probes/conv_item_timeline.py)
 };
@@ -104,6 +105,7 @@ struct EpiCtx {
     int b, kg;
     size_t HW, planeO;   // fp32 plane, record plane ((H + 2) * rec_pitch(W))
     int WpO;
+    double* st;          // ST epilogues: this wave's 16 (sum, sum of squares) slots of the item -- 8 quads of each of its two 32-cout tiles (wave-uniform)
     int dbg;             // probing (ConvRParams::dbg): bit 4 = the fp32 stores are skipped, bit 5 = the record stores are skipped (probes/conv_item_timeline.py --dbg)
 };
 
@@ -213,7 +215,11 @@ __device__ __forceinline__ void residual_into_acc(const float* res, int Cout, si
 // LLVM hoists 16 of them per tensor out of the persistent loop and spills them to VGPR lanes (two v_readlane per use).  What is left is
 // the CU's memory pipe: ~27 B/clk of stores, 256 KB (records) + 256 KB (fp32) per item.
 // 32-bit lane offsets: 20 HW < 2^32 (fp32) and 32 planeO < 2^32 (records), checked on the host (rec_image_ok).
-template <int NPX, int NROW, int MW, int ECS = 64>
+// ST (slow mode, round 5): the item's outputs also enter the GroupNorm statistics of the tensor (the producer of a POOLED norm's input,
+// include/mdtile.h "Slow mode (round 5)"): a lane adds its NROW x NPX x 4 values of every 4-cout quad in fp32, the half-wave's 32 pixels
+// are combined in fp64 and lane 0 of each half writes (sum, sum of squares) to E.st[(m * 8 + 2 g + kg) * 2 ..] -- combined over waves,
+// items and cout quads in a fixed order by k_conv_stats_partial (vae_norm.hip).  Separate kernel symbols: the ST = false code is untouched.
+template <int NPX, int NROW, int MW, int ECS = 64, bool ST = false>
 __device__ __forceinline__ void epilogue_item(const EpiCtx& E, const u32x4* ec, f32x16 (&acc)[MW][NROW][NPX], int mt_local0, int mt_global0,
                                               const int (&ys)[NROW], int x, bool x_ok, const ResRows<NROW>& next) {
     constexpr bool ACC_RES = NPX == 1;     // the residual is already in the accumulators (see ResRows); the sub-pixel kernel keeps the plain form
@@ -231,6 +237,13 @@ __device__ __forceinline__ void epilogue_item(const EpiCtx& E, const u32x4* ec, 
     const size_t lo_half = (size_t)Pn * pl16;
     const unsigned rlane = (kgo * (unsigned)E.planeO + (unsigned)(xc + mdt::REC_COL0)) * 16u;      // padded column 0 of ... + x
 
+    float st1[ST ? MW : 1][4], st2[ST ? MW : 1][4];
+    if constexpr (ST) {
+#pragma unroll
+        for (int m = 0; m < MW; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) st1[m][g] = st2[m][g] = 0.f;
+    }
     float rbuf[RB][NPX][16];              // (the sub-pixel kernel's residual rows: read here, in the plain form -- the decoder never gives it one)
     auto request_residual = [&](int u, float (&r)[RB][NPX][16]) {
         const int m = u / UPM, n0 = (u % UPM) * RB;
@@ -299,6 +312,16 @@ __device__ __forceinline__ void epilogue_item(const EpiCtx& E, const u32x4* ec, 
             const int n = n0 + nn;
             const int y = ys[n];
             if (!(y < E.H && x_ok)) continue;
+            if constexpr (ST) {
+#pragma unroll
+                for (int e = 0; e < NPX; ++e)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const float v = acc[m][n][e][q];
+                        st1[m][q >> 2] += v;
+                        st2[m][q >> 2] = fmaf(v, v, st2[m][q >> 2]);
+                    }
+            }
             if (E.y32 && !(E.dbg & 16)) {
                 const unsigned ro = lane32 + (unsigned)(y * E.W) * 4u;
                 if (whole) {
@@ -383,6 +406,25 @@ __device__ __forceinline__ void epilogue_item(const EpiCtx& E, const u32x4* ec, 
         if constexpr (NPX == 1) {
             if (E.res && next.on) residual_into_acc<NROW, MW, RB>(E.res, E.Cout, E.HW, E.H, E.W, E.kg, next, m, n0, acc);
         }
+    }
+    if constexpr (ST) {
+        const bool writer = (__lane_id() & 31) == 0;
+#pragma unroll
+        for (int m = 0; m < MW; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                double d1 = (double)st1[m][g], d2 = (double)st2[m][g];
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) {       // xor offsets < 32: inside the half-wave (the 32 pixels of a row)
+                    d1 += __shfl_xor(d1, off, 64);
+                    d2 += __shfl_xor(d2, off, 64);
+                }
+                if (writer) {
+                    double* o = E.st + ((m * 8 + 2 * g) + E.kg) * 2;
+                    o[0] = d1;
+                    o[1] = d2;
+                }
+            }
     }
 }
 

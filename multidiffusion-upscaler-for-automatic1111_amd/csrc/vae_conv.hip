@@ -15,6 +15,7 @@
 //   * nearest-2x upsample and the residual add are fused (source index >> 1 while staging; epilogue add).
 //   * XCD-aware block order: the BN-blocks of one pixel tile sit on the same XCD (same L2) back to back.
 #include "common.h"
+#include <algorithm>
 
 using namespace mdt;
 
@@ -233,7 +234,12 @@ bool conv_bf16x3_gn_supported(int cout, int cin, int ksize, int up);
 int conv_bf16x3_down2_launch(const float* d_x, const void* d_w_rec, const float* d_bias, float* d_y, int B, int cin, int cout, int Hin, int Win,
                              hipStream_t s);
 int conv_bf16x3_launch(const float* d_x, const void* d_w_rec, const float* d_bias, const float* d_res, float* d_y, int B, int cin,
-                       int cout, int H, int W, int up, const float* d_coef, hipStream_t s);
+                       int cout, int H, int W, int up, const float* d_coef, hipStream_t s, double* d_part = nullptr);
+bool conv_bf16x3_stats_supported(int cout, int cin, int ksize, int up);
+size_t conv_bf16x3_stats_part_doubles(int B, int cout, int H, int W);
+// vae_norm.hip
+int conv_stats_finish_launch(const double* d_cpart, int B, int cout, size_t HW, int units, int NCB, int QB, int groups, float* d_mean, float* d_var,
+                             void* d_gnws, hipStream_t s);
 bool conv_rec_narrow_eligible(int cout, int cin, int ksize);
 size_t conv_rec_narrow_packed_floats(int cin);
 int conv_rec_narrow_pack(const float* d_w_oihw, void* d_out, int cout, int cin, hipStream_t s);
@@ -244,7 +250,10 @@ size_t rec_plane_records(int H, int W);
 int rec_from_f32_launch(const float* d_x, const float* d_coef, void* d_rec, int B, int C, int H, int W, hipStream_t s);
 int rec_to_f32_launch(const void* d_rec, float* d_x, int B, int C, int H, int W, hipStream_t s);
 int conv_rec_launch(const void* d_xrec, const void* d_w_rec, const float* d_bias, const float* d_res, float* d_y32, void* d_yrec,
-                    const float* d_ycoef, int B, int cin, int cout, int H, int W, int up, hipStream_t s, const int* win = nullptr, int family = 0);
+                    const float* d_ycoef, int B, int cin, int cout, int H, int W, int up, hipStream_t s, const int* win = nullptr, int family = 0,
+                    double* d_part = nullptr);
+bool conv_rec_stats_in_epilogue(int B, int cin, int cout, int H, int W, int up);
+int conv_rec_stats_units(int H, int W, int up);
 // vae_conv1x1_bf16x3.hip
 bool conv1x1_bf16x3_eligible(int cout, int cin);
 size_t conv1x1_bf16x3_packed_floats(int cout, int cin);
@@ -327,6 +336,43 @@ extern "C" int mdtile_conv2d_gn(const float* d_x, const float* d_coef, const flo
                               as_stream(stream));
 }
 
+// ---- statistics of the output from the conv's own epilogue (slow mode: the input of a POOLED GroupNorm) ---------------------------------
+// d_ws = [ mdtile_gn_stats_ws_size(B, groups) bytes of fp64 stage-2 partials | the kernels' fp64 per-block partials ]; sized for the
+// finest block grid of the families (8 x 32 px x 128 couts, the fp32 hand-over kernel)
+extern "C" size_t mdtile_conv_stats_ws_size(int B, int cout, int H, int W, int groups) {
+    if (B <= 0 || cout <= 0 || H <= 0 || W <= 0 || groups <= 0) return 0;
+    // the record kernels write per WAVE (4 row groups of a 16 x 32 px item; sub-pixel kernel: 4 row groups x 2 row parities of an 8 x 32 INPUT px item)
+    size_t units = (size_t)((W + 31) / 32) * ((H + 7) / 8);
+    units = std::max(units, (size_t)conv_rec_stats_units(H, W, 0));
+    units = std::max(units, (size_t)conv_rec_stats_units(H + 1, W + 1, 1));
+    return mdtile_gn_stats_ws_size(B, groups) + (size_t)B * units * (round_up(cout, 128) / 128) * 64 * sizeof(double);
+}
+
+static bool stats_groups_ok(int cout, int groups) {
+    return groups > 0 && cout % groups == 0 && (cout / groups) % 4 == 0 && 128 % (cout / groups) == 0;
+}
+
+extern "C" int mdtile_conv2d_gn_stats_supported(int cout, int cin, int ksize, int flags, int groups) {
+    if (!mdtile_conv2d_gn_supported(cout, cin, ksize, flags, 0)) return 0;
+    return conv_bf16x3_stats_supported(cout, cin, ksize, 0) && stats_groups_ok(cout, groups) ? 1 : 0;
+}
+
+extern "C" int mdtile_conv2d_gn_stats(const float* d_x, const float* d_coef, const float* d_w_packed, const float* d_bias, const float* d_residual,
+                                      float* d_y, int B, int cin, int cout, int H, int W, int ksize, int flags, int groups, float* d_mean,
+                                      float* d_var, void* d_ws, mdtile_stream_t stream) {
+    MDT_CHECK_ARG(d_x && d_coef && d_w_packed && d_y && d_mean && d_var && d_ws, "mdtile_conv2d_gn_stats: null argument");
+    MDT_CHECK_ARG(B > 0 && B <= 65535 && cin > 0 && cout > 0 && H > 0 && W > 0, "mdtile_conv2d_gn_stats: bad shape B=%d cin=%d cout=%d H=%d W=%d", B, cin, cout, H, W);
+    MDT_CHECK_ARG(mdtile_conv2d_gn_stats_supported(cout, cin, ksize, flags, groups),
+                  "mdtile_conv2d_gn_stats: no statistics kernel for cout=%d cin=%d ksize=%d flags=%d groups=%d (use mdtile_conv2d_gn + mdtile_gn_stats)", cout, cin, ksize, flags, groups);
+    MDT_CHECK_ARG((size_t)H * W < (1u << 31), "mdtile_conv2d_gn_stats: input plane of 2^31 or more pixels");
+    double* d_part = reinterpret_cast<double*>(static_cast<char*>(d_ws) + mdtile_gn_stats_ws_size(B, groups));
+    hipStream_t s = as_stream(stream);
+    const int rc = conv_bf16x3_launch(d_x, d_w_packed + f32_packed_floats(cout, cin, ksize), d_bias, d_residual, d_y, B, cin, cout, H, W, 0, d_coef, s, d_part);
+    if (rc != MDTILE_OK) return rc;
+    const int units = ((W + 31) / 32) * ((H + 7) / 8);
+    return conv_stats_finish_launch(d_part, B, cout, (size_t)H * W, units, cout / 128, 32, groups, d_mean, d_var, d_ws, s);
+}
+
 // ---- record-image conv path (vae_conv_rec.hip) ----------------------------------------------------------------------
 extern "C" size_t mdtile_rec_size(int B, int C, int H, int W) {
     if (B <= 0 || C <= 0 || C % 32 != 0 || H <= 0 || W <= 0) return 0;
@@ -373,6 +419,34 @@ extern "C" int mdtile_conv2d_rec(const void* d_x_rec, const float* d_w_packed, c
                   "mdtile_conv2d_rec: the narrow (cout < 32) kernel writes fp32 only, no residual, no upsample (cout=%d)", cout);
     return conv_rec_launch(d_x_rec, d_w_packed + f32_packed_floats(cout, cin, 3), d_bias, d_residual, d_y, d_y_rec, d_y_coef, B, cin, cout,
                            H, W, up, as_stream(stream), nullptr, rec_family(flags));
+}
+
+extern "C" int mdtile_conv2d_rec_stats_supported(int cout, int cin, int ksize, int flags, int groups) {
+    return mdtile_conv2d_rec_supported(cout, cin, ksize, flags) && cout % 128 == 0 && stats_groups_ok(cout, groups) ? 1 : 0;
+}
+
+extern "C" int mdtile_conv2d_rec_stats(const void* d_x_rec, const float* d_w_packed, const float* d_bias, const float* d_residual, float* d_y,
+                                       int B, int cin, int cout, int H, int W, int flags, int groups, float* d_mean, float* d_var, void* d_ws,
+                                       mdtile_stream_t stream) {
+    MDT_CHECK_ARG(d_x_rec && d_w_packed && d_y && d_mean && d_var && d_ws, "mdtile_conv2d_rec_stats: null argument");
+    MDT_CHECK_ARG(mdtile_conv2d_rec_stats_supported(cout, cin, 3, flags, groups),
+                  "mdtile_conv2d_rec_stats: no statistics kernel for cout=%d cin=%d flags=%d groups=%d", cout, cin, flags, groups);
+    const int up = (flags & MDTILE_CONV_UPSAMPLE2X) ? 1 : 0;
+    MDT_CHECK_ARG(!up || (H % 2 == 0 && W % 2 == 0), "mdtile_conv2d_rec_stats: upsample2x needs even output size, got %dx%d", H, W);
+    MDT_CHECK_ARG(rec_image_ok(B, cin, up ? H / 2 : H, up ? W / 2 : W) && rec_image_ok(B, cout, H, W),
+                  "mdtile_conv2d_rec_stats: unsupported shape B=%d cin=%d cout=%d H=%d W=%d", B, cin, cout, H, W);
+    hipStream_t s = as_stream(stream);
+    const float* w = d_w_packed + f32_packed_floats(cout, cin, 3);
+    if (rec_family(flags) == 0 && !conv_rec_stats_in_epilogue(B, cin, cout, H, W, up)) {
+        // a launch of a few item rounds: the two-blocks-per-CU family gains more than the statistics pass costs (conv_rec_stats_in_epilogue)
+        const int rc = conv_rec_launch(d_x_rec, w, d_bias, d_residual, d_y, nullptr, nullptr, B, cin, cout, H, W, up, s);
+        return rc != MDTILE_OK ? rc : mdtile_gn_stats(d_y, B, cout, H * W, groups, d_mean, d_var, d_ws, stream);
+    }
+    MDT_CHECK_ARG(rec_family(flags) <= 1, "mdtile_conv2d_rec_stats: only the one-block-per-CU family leaves statistics (flags=%d)", flags);
+    double* d_part = reinterpret_cast<double*>(static_cast<char*>(d_ws) + mdtile_gn_stats_ws_size(B, groups));
+    const int rc = conv_rec_launch(d_x_rec, w, d_bias, d_residual, d_y, nullptr, nullptr, B, cin, cout, H, W, up, s, nullptr, 1, d_part);
+    if (rc != MDTILE_OK) return rc;
+    return conv_stats_finish_launch(d_part, B, cout, (size_t)H * W, conv_rec_stats_units(H, W, up), cout / 128, 32, groups, d_mean, d_var, d_ws, s);
 }
 
 // Nearest-2x + 3x3 conv of a WINDOW of the input record image (live-window narrowing of the decoder tiles, see include/mdtile.h)

@@ -42,6 +42,7 @@ struct ConvBParams {
     int ptiles, PX, NCB, NK;  // pixel tiles, tiles per row, cout blocks, 16-channel K-steps
     const float* coef;        // fused pre-activation (GNS kernels): [B][2][Cin] = per-channel scale a, shift s; x' = silu(a x + s)
     int perm;                 // channel order inside a K-step, see kstep_c0 / kstep_cj
+    double* gn_part;          // ST kernels: per-block partial (sum, sum of squares) of the OUTPUT per 4-cout quad, see the epilogue
 };
 
 constexpr int MAX_GN_CIN = 512;   // the fused pre-activation keeps a[Cin], s[Cin] in LDS
@@ -80,7 +81,11 @@ __device__ __host__ __forceinline__ int kstep_cj(int j, int perm) { return perm 
 // the same split-bf16 arithmetic.  Output tile 8 x 32 px, input halo tile 17 x 65; the LDS image keeps the two COLUMN PARITIES of a
 // row apart ([cg][row 17][parity 2][33]) so that the fragment of tap dx -- input columns 2 x + dx of 32 consecutive output px -- is
 // again 32 consecutive records (a stride-2 ds_read_b128 would be a 2-way bank conflict).  Zero padding only right / bottom.
-template <int MT, bool GNS, int S = 1>
+// ST = true (slow mode, round 5): the conv whose output feeds a POOLED GroupNorm (GroupNormParam.add_tile -> get_var_mean,
+// scripts/tilevae.py:207-215, 300-307) also leaves the statistics of that output: every block writes (sum, sum of squares) of its
+// BM couts x 8 x 32 px in 4-cout quads -- gn_part[(b * ptiles + ptile) * NCB + cb][BM / 4][2] fp64, combined in a fixed order by
+// k_conv_stats_partial / k_gn_final (vae_norm.hip): the separate pass that re-read the whole activation is gone.  y is bit-identical.
+template <int MT, bool GNS, int S = 1, bool ST = false>
 __global__ __launch_bounds__(512, (MT == 4 && S == 1) ? 4 : 2) void k_conv3x3_bf16x3(const ConvBParams P) {
     constexpr int TH_ = 8;
     constexpr bool WDMA = MT == 4, IB1 = MT == 4 || S == 2, TERM_MAJOR = MT == 4;   // (S = 2: the 72 KB halo tile exists once)
@@ -299,6 +304,7 @@ __global__ __launch_bounds__(512, (MT == 4 && S == 1) ? 4 : 2) void k_conv3x3_bf
             const int co = cbase + (q & 3) + 8 * (q >> 2);
             bq[q] = P.bias ? P.bias[co < P.Cout ? co : P.Cout - 1] : 0.0f;
         }
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};   // ST: this lane's part of the four quads of the tile (rows 8 j + 4 kg ..)
 #pragma unroll
         for (int n = 0; n < NROW; ++n) {
             const int y = y0 + wr * NROW + n;
@@ -313,9 +319,45 @@ __global__ __launch_bounds__(512, (MT == 4 && S == 1) ? 4 : 2) void k_conv3x3_bf
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const int co = cbase + (q & 3) + 8 * (q >> 2);
-                    if (co < P.Cout) P.y[o0 + (size_t)co * HW] = acc[m][n][q] + bq[q] + rq[q];
+                    const float v = acc[m][n][q] + bq[q] + rq[q];
+                    if (co < P.Cout) P.y[o0 + (size_t)co * HW] = v;
+                    if (ST) {                  // (the launcher only takes Cout % BM == 0 here: every cout of the block exists)
+                        s1[q >> 2] += v;
+                        s2[q >> 2] = fmaf(v, v, s2[q >> 2]);
+                    }
                 }
             }
+        }
+        if (ST) {
+            // a lane's fp32 sums cover 2 rows x 4 couts; from here on fp64 (an fp32 tree over the block would round at 1e-7 of the BLOCK's sum
+            // of squares, which var = E[x^2] - mean^2 amplifies by mean^2 / var).  The 32 pixels of a row sit in the 32 lanes of a
+            // half-wave: xor offsets < 32 stay inside it.
+            double d1[4], d2[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                d1[j] = (double)s1[j];
+                d2[j] = (double)s2[j];
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) {
+                    d1[j] += __shfl_xor(d1[j], off, 64);
+                    d2[j] += __shfl_xor(d2[j], off, 64);
+                }
+            }
+            if (l31 == 0) {
+                double2* sl = reinterpret_cast<double2*>(smem);      // the K loop ended behind a barrier: the operand stages are free
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sl[wr * (BM / 4) + (wm * 2 + m) * 8 + 2 * j + kg] = make_double2(d1[j], d2[j]);
+            }
+        }
+    }
+    if (ST) {
+        __syncthreads();
+        if (tid < BM / 2) {            // (quad, sum | sum of squares): the row groups of the block in a fixed order
+            const double* sl = reinterpret_cast<const double*>(smem);
+            double t = 0.0;
+#pragma unroll
+            for (int r = 0; r < WAVES_R; ++r) t += sl[r * (BM / 2) + tid];
+            P.gn_part[(((size_t)b * P.ptiles + ptile) * P.NCB + cb) * (BM / 2) + tid] = t;
         }
     }
 }
@@ -635,11 +677,21 @@ bool conv_bf16x3_gn_supported(int cout, int cin, int ksize, int up) {
     return conv_bf16x3_eligible(cout, cin, ksize) && !up && cin <= MAX_GN_CIN;
 }
 
+// statistics in the epilogue (k_conv3x3_bf16x3<4, true, 1, true>): 128-cout blocks with the fused pre-activation, whole blocks of couts
+bool conv_bf16x3_stats_supported(int cout, int cin, int ksize, int up) {
+    return conv_bf16x3_gn_supported(cout, cin, ksize, up) && conv_bf16x3_mt(cout) == 4 && cout % 128 == 0;
+}
+// doubles of the per-block partials: [B][ptiles][NCB][32 quads][2]
+size_t conv_bf16x3_stats_part_doubles(int B, int cout, int H, int W) {
+    return (size_t)B * ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * (cout / 128) * 64;
+}
+
 int conv_bf16x3_launch(const float* d_x, const void* d_w_rec, const float* d_bias, const float* d_res, float* d_y, int B, int cin,
-                       int cout, int H, int W, int up, const float* d_coef, hipStream_t s) {
+                       int cout, int H, int W, int up, const float* d_coef, hipStream_t s, double* d_part) {
     ConvBParams P;
     P.perm = conv_bf16x3_perm(cin);
     P.coef = d_coef;
+    P.gn_part = d_part;
     P.x = d_x; P.w = (const u32x4*)d_w_rec; P.bias = d_bias; P.res = d_res; P.y = d_y;
     P.B = B; P.Cin = cin; P.Cout = cout; P.H = H; P.W = W;
     P.Hin = up ? H / 2 : H; P.Win = up ? W / 2 : W; P.up = up;
@@ -660,8 +712,10 @@ int conv_bf16x3_launch(const float* d_x, const void* d_w_rec, const float* d_bia
     P.PX = (W + TW - 1) / TW;
     P.ptiles = P.PX * ((H + TH - 1) / TH);
     dim3 grid(((P.ptiles + 7) / 8) * 8 * P.NCB, B);
+    MDT_CHECK_ARG(!d_part || (MT == 4 && d_coef && cout % 128 == 0), "conv_bf16x3_launch: no statistics kernel for cout=%d", cout);
     if (MT == 4) {
-        if (d_coef) hipLaunchKernelGGL((k_conv3x3_bf16x3<4, true>), grid, block, 0, s, P);
+        if (d_coef && d_part) hipLaunchKernelGGL((k_conv3x3_bf16x3<4, true, 1, true>), grid, block, 0, s, P);
+        else if (d_coef) hipLaunchKernelGGL((k_conv3x3_bf16x3<4, true>), grid, block, 0, s, P);
         else hipLaunchKernelGGL((k_conv3x3_bf16x3<4, false>), grid, block, 0, s, P);
     } else {
         if (d_coef) hipLaunchKernelGGL((k_conv3x3_bf16x3<2, true>), grid, block, 0, s, P);
@@ -677,6 +731,7 @@ int conv_bf16x3_down2_launch(const float* d_x, const void* d_w_rec, const float*
     ConvBParams P;
     P.perm = conv_bf16x3_perm(cin);
     P.coef = nullptr;
+    P.gn_part = nullptr;
     P.x = d_x; P.w = (const u32x4*)d_w_rec; P.bias = d_bias; P.res = nullptr; P.y = d_y;
     P.B = B; P.Cin = cin; P.Cout = cout; P.H = (Hin - 2) / 2 + 1; P.W = (Win - 2) / 2 + 1;
     P.Hin = Hin; P.Win = Win; P.up = 0;

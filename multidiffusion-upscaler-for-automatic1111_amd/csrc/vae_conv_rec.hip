@@ -64,261 +64,16 @@ __device__ __forceinline__ void stagger_start(const ConvRParams& P, int wave) {
     while (__builtin_amdgcn_s_memrealtime() - t0 < d) __builtin_amdgcn_s_sleep(32);
 }
 
-template <int MW, int WM, int NROW>
-__global__ __launch_bounds__(512, 2) void k_conv3x3_rec(const ConvRParams P) {
-    constexpr int WR = 8 / WM, TH = WR * NROW, MT = MW * WM, HN = NROW / 2;
-    constexpr int ROWS = TH + 2, COLS = 34;
-    using IS = InStage<ROWS>;
-    constexpr int W_REC = 2 * 3 * MT * 64;              // [hl][dx][mt][lane]
-    constexpr int W_DMA = W_REC / 64;
-    constexpr int W_PW = (W_DMA + 7) / 8;
-    __shared__ u32x4 smem[2 * IS::PAD + 3 * W_REC + 2 * EC_REC];
-    u32x4* const in_l = smem;
-    u32x4* const w_l = smem + 2 * IS::PAD;
-    u32x4* const ec_l = smem + 2 * IS::PAD + 3 * W_REC;     // per-channel epilogue constants, two buffers (item parity)
-
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kg = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave % WM, wr = wave / WM;
-    const int Hp = P.H + 2, Wp = rec_pitch(P.W), Pn = P.Cin >> 3;
-    const size_t plane = (size_t)Hp * Wp;
-
-    // work -> (sample, pixel tile, cout block).  Workgroups go to XCDs round-robin (id % 8) and grid % 8 == 0 whenever a block
-    // sees more than one item, so `work % 8` is this block's XCD for all its items: all cout blocks of a pixel tile stay on one L2.
-    const int per_img = ((P.ptiles + 7) / 8) * 8 * P.NCB, total = per_img * P.B;
-    auto decode = [&](int work, WorkItem& it) -> bool {
-        it.b = work / per_img;
-        const int r = work - it.b * per_img, xcd = r & 7, slot = r >> 3;
-        const int ptile = (slot / P.NCB) * 8 + xcd;
-        it.cb = slot % P.NCB;
-        const int py = ptile / P.PX, px = ptile - py * P.PX;
-        it.y0 = py * TH;
-        it.x0 = px * 32;
-        return ptile < P.ptiles;
-    };
-    auto next_valid = [&](int work, WorkItem& it) -> int {   // first item >= work (stride grid) that is a real tile, or >= total
-        while (work < total && !decode(work, it)) work += gridDim.x;
-        return work;
-    };
-
-    // input DMA map: wave-instruction di = wave + 8 i covers LDS records [64 di, 64 di + 64) of a stage; hl = di / HALF_DMA
-    auto make_ioff = [&](const WorkItem& it, unsigned (&ioff)[IS::PW]) {   // byte offsets inside the (K-step, hl) pair of planes
-        int ln = lane;
-        asm volatile("" : "+v"(ln));      // the (g, r, c) of a piece are re-derived per item (~10 VALU each): kept across the persistent loop they are
-                                          // 15 registers that the epilogue's peak (accumulators + two residual buffers) pushes into scratch
-#pragma unroll
-        for (int i = 0; i < IS::PW; ++i) {
-            const int di = wave + 8 * i;
-            int s = (di % IS::HALF_DMA) * 64 + ln;
-            if (s >= IS::HALF) s = IS::HALF - 1;            // pad lanes shadow the last record (they land in the pad area)
-            const int g = s / (ROWS * COLS), p = s - g * (ROWS * COLS);
-            const int r = p / COLS, c = p - r * COLS;
-            int pr = it.y0 + r, pc = it.x0 + c;             // padded coordinates (image row y0 + r - 1, image column x0 + c - 1)
-            pr = pr < Hp ? pr : Hp - 1;                     // ragged block edge: clamp onto the zero border
-            pc = (pc < P.W + 1 ? pc : P.W + 1) + REC_COL0;  // (column of the record image: the left border sits at REC_COL0)
-            ioff[i] = (unsigned)(((size_t)g * plane + (size_t)pr * Wp + pc) * 16);
-        }
-    };
-    auto issue_input = [&](const WorkItem& it, const unsigned (&ioff)[IS::PW], int k, int stage) {
-        const char* xb = reinterpret_cast<const char*>(P.x + (size_t)it.b * 2 * Pn * plane);
-#pragma unroll
-        for (int i = 0; i < IS::PW; ++i) {
-            const int di = wave + 8 * i;
-            if (di < IS::DMA) {
-                const char* base = xb + ((size_t)(di / IS::HALF_DMA) * Pn + 2 * (size_t)k) * plane * 16;   // wave-uniform
-                dma16(base, ioff[i], in_l + stage * IS::PAD + di * 64);
-            }
-        }
-    };
-    const unsigned lane16 = lane * 16;
-    auto issue_weights = [&](const WorkItem& it, int ph, int ring) {
-        const char* wsrc = reinterpret_cast<const char*>(P.w + (size_t)it.cb * P.NK * 3 * W_REC);
-#pragma unroll
-        for (int i = 0; i < W_PW; ++i)
-            if (wave + 8 * i < W_DMA) {
-                const char* base = wsrc + ((size_t)ph * W_REC + (wave + 8 * i) * 64) * 16;
-                dma16(base, lane16, w_l + ring * W_REC + (wave + 8 * i) * 64);
-            }
-    };
-
-    // epilogue constants of an item's BM couts: waves 0 / 1 / 2 fetch bias / a / s (512 B each; the upper lanes repeat the
-    // lower ones into the pad half of the 1 KB slot)
-    const unsigned lane16h = (lane % (MT * 8)) * 16;      // MT * 32 floats = MT * 8 lanes x 16 B; the other lanes repeat them
-    auto issue_consts = [&](const WorkItem& it, int par) {
-        if (wave == 0 && P.bias) dma16(reinterpret_cast<const char*>(P.bias + it.cb * (MT * 32)), lane16h, ec_l + par * EC_REC);
-        if ((wave == 1 || wave == 2) && P.yrec && P.coef)
-            dma16(reinterpret_cast<const char*>(P.coef + ((size_t)it.b * 2 + (wave - 1)) * P.Cout + it.cb * (MT * 32)), lane16h,
-                  ec_l + par * EC_REC + wave * 64);
-    };
-
-    bf16x8 fw[2][MW][2];   // [set][m][hl]
-    bf16x8 fx[2][HN][2];   // [set][row of the half-step][hl]
-    const int wfrag = wm * MW * 64 + lane;                       // + ((hl*3 + dx)*MT + m)*64
-    const int xfrag = (kg * ROWS + wr * NROW) * COLS + l31;      // + hl*HALF_PAD + (n + dy)*COLS + dx
-    auto load_fw = [&](int set, int ring, int dx) {
-        const u32x4* wst = w_l + ring * W_REC + wfrag;
-#pragma unroll
-        for (int m = 0; m < MW; ++m)
-#pragma unroll
-            for (int hl = 0; hl < 2; ++hl) fw[set][m][hl] = __builtin_bit_cast(bf16x8, wst[((hl * 3 + dx) * MT + m) * 64]);
-    };
-    auto load_fx = [&](int set, int stage, int dy, int dx, int h) {
-        const u32x4* ist = in_l + stage * IS::PAD + xfrag + (dy + h * HN) * COLS + dx;
-#pragma unroll
-        for (int n = 0; n < HN; ++n)
-#pragma unroll
-            for (int hl = 0; hl < 2; ++hl) fx[set][n][hl] = __builtin_bit_cast(bf16x8, ist[hl * IS::HALF_PAD + n * COLS]);
-    };
-
-    WorkItem cur, nxt;
-    int work = next_valid(blockIdx.x, cur);
-    if (work >= total) return;
-    unsigned ioff[IS::PW];
-    make_ioff(cur, ioff);
-    issue_input(cur, ioff, 0, 0);
-    issue_weights(cur, 0, 0);
-    issue_weights(cur, 1, 1);
-    issue_consts(cur, 0);
-    stagger_start(P, wave);
-    const int nph = P.NK * 3;
-    int par = 0;
-
-    // probing (MDTILE_REC_DBG bit 3 + MDTILE_REC_STAMPS=<device address>): block 0 records s_memtime per wave and item at
-    //   0 item start (behind the barrier) | 1 K loop done | 2 epilogue code done (stores issued) | 4 vmcnt(0) + barrier of the next item passed
-    unsigned long long* const stamps = (pdbg(P.dbg) & 8) && P.census && blockIdx.x == 0 ? reinterpret_cast<unsigned long long*>(P.census) : nullptr;
-    int item_no = 0;
-    auto stamp = [&](int k) {
-        if (stamps && lane == 0 && item_no < 64) stamps[(item_no * 8 + wave) * 8 + k] = __builtin_readcyclecounter();
-    };
-    // a conv2's residual arrives in the accumulators (conv_rec_common.h: ResRows): the first item's rows are requested here, every later
-    // item's by the epilogue of the item before it
-    f32x16 acc[MW][NROW][1];
-    const bool res_in_acc = P.res != nullptr && !(pdbg(P.dbg) & 1);
-    auto res_rows = [&](const WorkItem& it, bool on) {
-        ResRows<NROW> R;
-        R.on = on; R.b = it.b; R.mt_global0 = it.cb * MT + wm * MW;
-#pragma unroll
-        for (int n = 0; n < NROW; ++n) R.ys[n] = it.y0 + wr * NROW + n;
-        int le = lane;
-        asm volatile("" : "+v"(le));
-        R.x = it.x0 + (le & 31);
-        R.x_ok = R.x < P.W;
-        return R;
-    };
-    if (res_in_acc) {
-        const ResRows<NROW> R0 = res_rows(cur, true);
-#pragma unroll
-        for (int m = 0; m < MW; ++m) residual_into_acc<NROW, MW, NROW>(P.res, P.Cout, (size_t)P.H * P.W, P.H, P.W, kg, R0, m, 0, acc);
-    }
-    while (true) {
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces of the item's first operands have landed (and the residual rows)
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (item_no > 0) { --item_no; stamp(4); ++item_no; }
-        stamp(0);
-        load_fw(0, 0, 0);
-        load_fx(0, 0, 0, 0, 0);
-        const int work_n = next_valid(work + gridDim.x, nxt);
-        unsigned ioff_n[IS::PW];
-        if (work_n < total) make_ioff(nxt, ioff_n);      // (outside the unrolled K loop: keeps its body under the unroll budget)
-
-        if (!res_in_acc) {
-#pragma unroll
-            for (int m = 0; m < MW; ++m)
-#pragma unroll
-                for (int n = 0; n < NROW; ++n)
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) acc[m][n][0][q] = 0.0f;
-        }
-
-        // one trip = 2 K-steps = 6 phases = 18 steps = 36 half-steps: ring slot (= dy), input stage (= kk) and both register-set
-        // parities are compile-time constants inside the unrolled body
-        for (int k2 = 0; k2 < P.NK; k2 += 2) {
-#pragma unroll
-            for (int t = 0; t < 36; ++t) {
-                const int kk = t / 18, dy = (t / 6) % 3, dx = (t / 2) % 3, h = t & 1;
-                const int k = k2 + kk, ph = k * 3 + dy;
-                const int xs = t & 1, ws = (t >> 1) & 1;
-                // ---- the NEXT half-step's fragments go out first
-                MDT_PIN();
-                if (h == 0) {
-                    load_fx(xs ^ 1, kk, dy, dx, 1);
-                } else if (t < 35) {
-                    const int t1 = t + 1, kk1 = t1 / 18, dy1 = (t1 / 6) % 3, dx1 = (t1 / 2) % 3;
-                    load_fw(ws ^ 1, dy1, dx1);
-                    load_fx(xs ^ 1, kk1, dy1, dx1, 0);
-                } else if (k2 + 2 < P.NK) {
-                    load_fw(ws ^ 1, 0, 0);
-                    load_fx(xs ^ 1, 0, 0, 0, 0);
-                }
-                MDT_PIN();
-                // ---- this half-step's MFMAs: term-major over its accumulators (a dependent MFMA is MW*HN issues away)
-#pragma unroll
-                for (int term = 0; term < 3; ++term)
-#pragma unroll
-                    for (int n = 0; n < HN; ++n)
-#pragma unroll
-                        for (int m = 0; m < MW; ++m)
-                            acc[m][h * HN + n][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ws][m][term == 0 ? 1 : 0], fx[xs][n][term == 1 ? 1 : 0],
-                                                                                            acc[m][h * HN + n][0], 0, 0, 0);   // w_lo x_hi, w_hi x_lo, w_hi x_hi
-                MDT_PIN();
-                if (dx == 0 && h == 1) {
-                    // Pieces this wave has in flight, oldest first: weight chunk ph+1 (issued behind the previous barrier) and, at
-                    // dy = 1, the input tile of K-step k+1 issued right after it.  The weights are read from the end of this phase
-                    // on, the input tile only from the end of the dy = 2 phase: at dy = 1 the IS::PW youngest pieces (every wave
-                    // issues exactly that many, IS::DMA % 8 == 0) may stay in flight -- a whole extra phase for their HBM round trip.
-                    static_assert(IS::DMA % 8 == 0 && IS::PW == 5, "the counted wait below assumes 5 input pieces per wave");
-                    if (dy == 1 && k + 1 < P.NK) __builtin_amdgcn_s_waitcnt(0x0F75);   // vmcnt(5)
-                    else __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0)
-                    asm volatile("" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    asm volatile("" ::: "memory");
-                }
-                // DMA issue of this phase (~10 scalar / VMEM instructions per piece), staggered between the two waves that share a
-                // SIMD (w and w + 4): waves 0-3 right behind the barrier, waves 4-7 one half-step later -- while one of the pair
-                // issues its pieces the other one keeps the matrix pipe fed.
-                // Ring slot of chunk ph+2 = the one chunk ph-1 held: every wave finished reading it before the barrier.
-                if ((dx == 0 && h == 1 && wave < 4) || (dx == 1 && h == 0 && wave >= 4)) {
-                    if (ph + 2 < nph) issue_weights(cur, ph + 2, (dy + 2) % 3);
-                    if (dy == 0 && k + 1 < P.NK) issue_input(cur, ioff, k + 1, (kk + 1) & 1);
-                    if (kk == 1 && dy == 2 && k + 1 == P.NK && work_n < total) {
-                        // last phase of the item: ring slots 0 / 1 and input stage 0 are out of use (NK is even) -> the next
-                        // item's first operands go there now and land under the remaining MFMAs and the epilogue
-                        issue_input(nxt, ioff_n, 0, 0);
-                        issue_weights(nxt, 0, 0);
-                        issue_weights(nxt, 1, 1);
-                        issue_consts(nxt, par ^ 1);
-                    }
-                }
-            }
-        }
-
-        stamp(1);
-        EpiCtx E;
-        E.res = P.res; E.y32 = P.y32; E.yrec = P.yrec;
-        E.has_bias = P.bias != nullptr; E.has_act = P.yrec != nullptr && P.coef != nullptr;
-        E.Cout = P.Cout; E.H = P.H; E.W = P.W; E.b = cur.b; E.kg = kg;
-        E.HW = (size_t)P.H * P.W; E.planeO = plane; E.WpO = Wp;
-        E.dbg = pdbg(P.dbg);
-        int le = lane;
-        asm volatile("" : "+v"(le));      // (re-derived: a separate l31 kept alive through the epilogue goes to scratch)
-        const int x = cur.x0 + (le & 31);
-        int ys[NROW];
-#pragma unroll
-        for (int n = 0; n < NROW; ++n) ys[n] = cur.y0 + wr * NROW + n;
-        if (!(pdbg(P.dbg) & 1)) {
-            epilogue_item<1, NROW, MW>(E, ec_l + par * EC_REC, acc, wm * MW, cur.cb * MT + wm * MW, ys, x, x < P.W, res_rows(nxt, work_n < total));
-        }
-        stamp(2);
-        ++item_no;
-        if (work_n >= total) break;
-        work = work_n;
-        cur = nxt;
-        par ^= 1;
-        for (int i = 0; i < IS::PW; ++i) ioff[i] = ioff_n[i];
-    }
-}
+#define MDT_REC_KERNEL k_conv3x3_rec
+#define MDT_REC_ST 0
+#include "vae_conv_rec_direct_body.h"
+#undef MDT_REC_KERNEL
+#undef MDT_REC_ST
+#define MDT_REC_KERNEL k_conv3x3_rec_st
+#define MDT_REC_ST 1
+#include "vae_conv_rec_direct_body.h"
+#undef MDT_REC_KERNEL
+#undef MDT_REC_ST
 
 // =====================================================================================================================
 // nearest-2x upsample + 3x3 conv in sub-pixel form (four 2x2 convs on the un-upsampled grid, see vae_conv_bf16x3.hip
@@ -328,221 +83,16 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rec(const ConvRParams P) {
 // Weight chunk [hl][bb][v][mt][lane] per (a, cb, k, u) in a 3-slot ring.  Persistent like k_conv3x3_rec; an item has 2 NK
 // phases, which need not be a multiple of 3, so the ring position of an item's first chunk (r0) rotates from item to item:
 // the next item's chunks 0 / 1 go to the two slots the last phase is NOT reading.
-__global__ __launch_bounds__(512, 2) void k_upconv_rec(const ConvRParams P) {
-    constexpr int MT = 4, MW = 2, WM = 2, NROW = 2, TH = 8;
-    constexpr int ROWS = TH + 2, COLS = 34;
-    using IS = InStage<ROWS>;
-    constexpr int W_REC = 2 * 2 * 2 * MT * 64, W_DMA = W_REC / 64, W_PW = W_DMA / 8;
-    __shared__ u32x4 smem[2 * IS::PAD + 3 * W_REC + 2 * EC_REC];
-    u32x4* const in_l = smem;
-    u32x4* const w_l = smem + 2 * IS::PAD;
-    u32x4* const ec_l = smem + 2 * IS::PAD + 3 * W_REC;
-
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kg = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave % WM, wr = wave / WM;
-    const int Hp = P.HinF + 2, Wp = rec_pitch(P.WinF), Pn = P.Cin >> 3;      // pitches of the WHOLE input image; items tile its window
-    const size_t plane = (size_t)Hp * Wp;
-
-    struct Item {
-        int b, cb, a, y0, x0;   // y0, x0: INPUT coordinates (relative to the window)
-    };
-    const int per = P.NCB * 2, per_img = ((P.ptiles + 7) / 8) * 8 * per, total = per_img * P.B;
-    auto decode = [&](int work, Item& it) -> bool {
-        it.b = work / per_img;
-        const int r = work - it.b * per_img, xcd = r & 7, slot = r >> 3;
-        const int ptile = (slot / per) * 8 + xcd, rem = slot % per;
-        it.cb = rem >> 1;
-        it.a = rem & 1;
-        const int py = ptile / P.PX, px = ptile - py * P.PX;
-        it.y0 = py * TH;
-        it.x0 = px * 32;
-        return ptile < P.ptiles;
-    };
-    auto next_valid = [&](int work, Item& it) -> int {
-        while (work < total && !decode(work, it)) work += gridDim.x;
-        return work;
-    };
-    auto make_ioff = [&](const Item& it, unsigned (&ioff)[IS::PW]) {
-#pragma unroll
-        for (int i = 0; i < IS::PW; ++i) {
-            const int di = wave + 8 * i;
-            int s = (di % IS::HALF_DMA) * 64 + lane;
-            if (s >= IS::HALF) s = IS::HALF - 1;
-            const int g = s / (ROWS * COLS), p = s - g * (ROWS * COLS);
-            const int r = p / COLS, c = p - r * COLS;
-            int pr = P.iy0[it.b & (REC_WIN_MAXB - 1)] + it.y0 + r, pc = P.ix0[it.b & (REC_WIN_MAXB - 1)] + it.x0 + c;     // inside the window's own border: the image's real neighbours
-            pr = pr < Hp ? pr : Hp - 1;
-            pc = (pc < P.WinF + 1 ? pc : P.WinF + 1) + REC_COL0;
-            ioff[i] = (unsigned)(((size_t)g * plane + (size_t)pr * Wp + pc) * 16);
-        }
-    };
-    auto issue_input = [&](const Item& it, const unsigned (&ioff)[IS::PW], int k, int stage) {
-        const char* xb = reinterpret_cast<const char*>(P.x + (size_t)it.b * 2 * Pn * plane);
-#pragma unroll
-        for (int i = 0; i < IS::PW; ++i) {
-            const int di = wave + 8 * i;
-            if (di < IS::DMA) {
-                const char* base = xb + ((size_t)(di / IS::HALF_DMA) * Pn + 2 * (size_t)k) * plane * 16;
-                dma16(base, ioff[i], in_l + stage * IS::PAD + di * 64);
-            }
-        }
-    };
-    const int nph = P.NK * 2;
-    const unsigned lane16 = lane * 16;
-    auto issue_weights = [&](const Item& it, int ph, int ring) {
-        const char* wsrc = reinterpret_cast<const char*>(P.w + ((size_t)it.a * P.NCB + it.cb) * nph * W_REC);
-#pragma unroll
-        for (int i = 0; i < W_PW; ++i) {
-            const char* base = wsrc + ((size_t)ph * W_REC + (wave + 8 * i) * 64) * 16;
-            dma16(base, lane16, w_l + ring * W_REC + (wave + 8 * i) * 64);
-        }
-    };
-    const unsigned lane16h = (lane & 31) * 16;
-    auto issue_consts = [&](const Item& it, int par) {
-        if (wave == 0 && P.bias) dma16(reinterpret_cast<const char*>(P.bias + it.cb * (MT * 32)), lane16h, ec_l + par * EC_REC);
-        if ((wave == 1 || wave == 2) && P.yrec && P.coef)
-            dma16(reinterpret_cast<const char*>(P.coef + ((size_t)it.b * 2 + (wave - 1)) * P.Cout + it.cb * (MT * 32)), lane16h,
-                  ec_l + par * EC_REC + wave * 64);
-    };
-
-    bf16x8 fw[2][MW][2];     // [set][m][hl]   weight tiles of one combo-step
-    bf16x8 fx[2][NROW][2];   // [set][n][hl]   input rows of one column shift
-    const int wfrag = wm * MW * 64 + lane;
-    auto load_fw = [&](int set, int ring, int c) {
-        const int bb = c >> 1, v = ((c + 1) >> 1) - bb;           // c: 0 -> (0, 0), 1 -> (0, 1), 2 -> (1, 0), 3 -> (1, 1)
-        const u32x4* wst = w_l + ring * W_REC + wfrag;
-#pragma unroll
-        for (int m = 0; m < MW; ++m)
-#pragma unroll
-            for (int hl = 0; hl < 2; ++hl) fw[set][m][hl] = __builtin_bit_cast(bf16x8, wst[(((hl * 2 + bb) * 2 + v) * MT + m) * 64]);
-    };
-    auto load_fx = [&](int set, int xfrag, int stage, int u, int s) {
-        const u32x4* ist = in_l + stage * IS::PAD + xfrag + u * COLS + s;
-#pragma unroll
-        for (int n = 0; n < NROW; ++n)
-#pragma unroll
-            for (int hl = 0; hl < 2; ++hl) fx[set][n][hl] = __builtin_bit_cast(bf16x8, ist[hl * IS::HALF_PAD + n * COLS]);
-    };
-
-    Item cur, nxt;
-    int work = next_valid(blockIdx.x, cur);
-    if (work >= total) return;
-    unsigned ioff[IS::PW];
-    make_ioff(cur, ioff);
-    issue_input(cur, ioff, 0, 0);
-    issue_weights(cur, 0, 0);
-    issue_weights(cur, 1, 1);
-    issue_consts(cur, 0);
-    stagger_start(P, wave);
-    int par = 0, r0 = 0;       // constants-buffer parity, ring slot of this item's chunk 0
-
-    while (true) {
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const int xfrag = (kg * ROWS + wr * NROW + cur.a) * COLS + l31;   // halo row of output row n at tap row u: + (n + u)*COLS
-        int rs[3];                                                        // ring slot of local phase p: rs[p % 3]
-#pragma unroll
-        for (int i = 0; i < 3; ++i) rs[i] = (r0 + i) % 3;
-        load_fw(0, rs[0], 0);
-        load_fx(0, xfrag, 0, 0, 0);
-        const int work_n = next_valid(work + gridDim.x, nxt);
-        unsigned ioff_n[IS::PW];
-        if (work_n < total) make_ioff(nxt, ioff_n);
-        const int r0_n = (r0 + nph) % 3;                                  // = (slot of the last chunk + 1) % 3
-
-        f32x16 acc[MW][NROW][2];   // [m][n][bb]
-#pragma unroll
-        for (int m = 0; m < MW; ++m)
-#pragma unroll
-            for (int n = 0; n < NROW; ++n)
-#pragma unroll
-                for (int bb = 0; bb < 2; ++bb)
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) acc[m][n][bb][q] = 0.0f;
-
-        // one trip = 3 K-steps = 6 phases = 24 combo-steps: the register sets are compile-time (fw set = combo-step parity; fx set =
-        // parity of the running shift counter 3*phase + s) and so is the ring index modulo the item's r0.  NK % 3 != 0: the surplus
-        // K-steps of the last trip are skipped (wave-uniform branch).
-        for (int k3 = 0; k3 < P.NK; k3 += 3) {
-#pragma unroll
-            for (int t = 0; t < 24; ++t) {
-                const int pl_ = t >> 2, c = t & 3;                 // local phase 0..5, combo-step
-                const int kk = pl_ >> 1, u = pl_ & 1, s = (c + 1) >> 1, bb = c >> 1;
-                const int k = k3 + kk, ph = k * 2 + u;
-                const int ws = t & 1, xs = (3 * pl_ + s) & 1;
-                if (k < P.NK) {
-                    MDT_PIN();
-                    if (c < 3) {
-                        load_fw(ws ^ 1, rs[pl_ % 3], c + 1);
-                        if (c != 1) load_fx(xs ^ 1, xfrag, k & 1, u, s + 1);
-                    } else {
-                        const int pl1 = (pl_ + 1) % 6, kk1 = pl1 >> 1, u1 = pl1 & 1;
-                        const int k1 = (pl_ < 5 ? k3 : k3 + 3) + kk1;
-                        if (k1 < P.NK) {
-                            load_fw(ws ^ 1, rs[pl1 % 3], 0);
-                            load_fx(xs ^ 1, xfrag, k1 & 1, u1, 0);
-                        }
-                    }
-                    MDT_PIN();
-#pragma unroll
-                    for (int term = 0; term < 3; ++term)
-#pragma unroll
-                        for (int n = 0; n < NROW; ++n)
-#pragma unroll
-                            for (int m = 0; m < MW; ++m)
-                                acc[m][n][bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ws][m][term == 0 ? 1 : 0], fx[xs][n][term == 1 ? 1 : 0],
-                                                                                        acc[m][n][bb], 0, 0, 0);
-                    MDT_PIN();
-                    if (c == 1) {
-                        __builtin_amdgcn_s_waitcnt(0x0F70);
-                        asm volatile("" ::: "memory");
-                        __builtin_amdgcn_s_barrier();
-                        asm volatile("" ::: "memory");
-                    }
-                    // staggered DMA issue (see k_conv3x3_rec): waves 0-3 behind the barrier, waves 4-7 one combo-step later
-                    if ((c == 1 && wave < 4) || (c == 2 && wave >= 4)) {
-                        if (ph + 2 < nph) issue_weights(cur, ph + 2, rs[(pl_ + 2) % 3]);
-                        if (u == 0 && k + 1 < P.NK) issue_input(cur, ioff, k + 1, (k + 1) & 1);
-                        if (ph + 1 == nph && work_n < total) {
-                            // last phase: the two ring slots it does not read and input stage 0 (NK is even: the last K-step sits in
-                            // stage 1) take the next item's first operands
-                            issue_input(nxt, ioff_n, 0, 0);
-                            issue_weights(nxt, 0, r0_n);
-                            issue_weights(nxt, 1, (r0_n + 1) % 3);
-                            issue_consts(nxt, par ^ 1);
-                        }
-                    }
-                }
-            }
-        }
-
-        EpiCtx E;
-        E.res = P.res; E.y32 = P.y32; E.yrec = P.yrec;
-        E.has_bias = P.bias != nullptr; E.has_act = P.yrec != nullptr && P.coef != nullptr;
-        E.Cout = P.Cout; E.H = P.H; E.W = P.W; E.b = cur.b; E.kg = kg;
-        E.HW = (size_t)P.H * P.W; E.planeO = (size_t)(P.H + 2) * rec_pitch(P.W); E.WpO = rec_pitch(P.W); E.dbg = pdbg(P.dbg);
-        const int xi = cur.x0 + l31;
-        int ys[NROW];
-#pragma unroll
-        for (int n = 0; n < NROW; ++n) {
-            const int yi = cur.y0 + wr * NROW + n;
-            ys[n] = yi < P.Hin ? 2 * yi + cur.a : P.H;      // rows past the input's last row: marked invalid
-        }
-        if (!(pdbg(P.dbg) & 1)) {
-            epilogue_item<2, NROW, MW>(E, ec_l + par * EC_REC, acc, wm * MW, cur.cb * MT + wm * MW, ys, 2 * xi, xi < P.Win, ResRows<NROW>{});
-        }
-        if (work_n >= total) break;
-        work = work_n;
-        cur = nxt;
-        par ^= 1;
-        r0 = r0_n;
-#pragma unroll
-        for (int i = 0; i < IS::PW; ++i) ioff[i] = ioff_n[i];
-    }
-}
+#define MDT_REC_KERNEL k_upconv_rec
+#define MDT_REC_ST 0
+#include "vae_conv_rec_upconv_body.h"
+#undef MDT_REC_KERNEL
+#undef MDT_REC_ST
+#define MDT_REC_KERNEL k_upconv_rec_st
+#define MDT_REC_ST 1
+#include "vae_conv_rec_upconv_body.h"
+#undef MDT_REC_KERNEL
+#undef MDT_REC_ST
 
 // =====================================================================================================================
 // fp32 NCHW -> record image (+ optional fixed-statistics GroupNorm + SiLU): entry points of the record path (conv_in /
@@ -672,9 +222,32 @@ int rec_to_f32_launch(const void* d_rec, float* d_x, int B, int C, int H, int W,
 
 // win (sub-pixel upsample kernel only, else null): {HinF, WinF, y0[0], x0[0], ..., y0[7], x0[7]} -- d_xrec is the record image of
 // [B, cin, HinF, WinF] and image b's conv reads its window [y0[b & 7] : .. + H/2, x0[b & 7] : .. + W/2]  (all 8 slots filled)
+// statistics in the epilogue: one-block-per-CU kernels of the 128-cout family only.  A launch the cost model would hand to the two-blocks
+// family (a few item rounds: the 278 x 278 level of the 8K decode) gains more from that family than from dropping the statistics pass.
+bool conv_rec_stats_in_epilogue(int B, int cin, int cout, int H, int W, int up) {
+    if (cout % 128 != 0 || !rec_persistent()) return false;
+    const int cus = num_cus() / 8 * 8;
+    const int hin = up ? H / 2 : H, win = up ? W / 2 : W, per = (cout / 128) * (up ? 2 : 1);
+    const long long px = (win + 31) / 32;
+    const long long items16 = (px * ((hin + (up ? 7 : 15)) / (up ? 8 : 16)) + 7) / 8 * 8 * per * B;
+    const long long items8 = (px * ((hin + (up ? 3 : 7)) / (up ? 4 : 8)) + 7) / 8 * 8 * per * B;
+    (void)cin;
+    return !rec_two_blocks(items16, items8, cus, up, 0);
+}
+// units of the per-wave partials a statistics launch writes (conv_stats_finish_launch): [B][units][NCB][32 quads][2] doubles
+int conv_rec_stats_units(int H, int W, int up) {
+    return up ? ((W / 2 + 31) / 32) * ((H / 2 + 7) / 8) * 8 : ((W + 31) / 32) * ((H + 15) / 16) * 4;
+}
+
 int conv_rec_launch(const void* d_xrec, const void* d_w_rec, const float* d_bias, const float* d_res, float* d_y32, void* d_yrec,
-                    const float* d_ycoef, int B, int cin, int cout, int H, int W, int up, hipStream_t s, const int* win, int family) {
+                    const float* d_ycoef, int B, int cin, int cout, int H, int W, int up, hipStream_t s, const int* win, int family,
+                    double* d_part) {
     ConvRParams P;
+    P.gn_part = d_part;
+    if (d_part) {
+        MDT_CHECK_ARG(cout % 128 == 0 && rec_persistent(), "conv_rec_launch: no statistics kernel for cout=%d", cout);
+        family = 1;
+    }
     P.x = (const u32x4*)d_xrec; P.w = (const u32x4*)d_w_rec; P.bias = d_bias; P.res = d_res; P.y32 = d_y32;
     P.yrec = (u32x4*)d_yrec; P.coef = d_ycoef;
     P.B = B; P.Cin = cin; P.Cout = cout; P.H = H; P.W = W;
@@ -716,7 +289,8 @@ int conv_rec_launch(const void* d_xrec, const void* d_w_rec, const float* d_bias
         const int cus = num_cus();
         stagger(items, cus, (unsigned)P.NK * 400u + 2000u);
         dim3 grid((unsigned)((items < cus || !rec_persistent()) ? items : cus / 8 * 8)), block(512);
-        hipLaunchKernelGGL(k_upconv_rec, grid, block, 0, s, P);
+        if (d_part) hipLaunchKernelGGL(k_upconv_rec_st, grid, block, 0, s, P);
+        else hipLaunchKernelGGL(k_upconv_rec, grid, block, 0, s, P);
         MDT_LAUNCH_CHECK();
         return MDTILE_OK;
     }
@@ -726,7 +300,8 @@ int conv_rec_launch(const void* d_xrec, const void* d_w_rec, const float* d_bias
     const int cus = num_cus();                    // one block per CU (155 KB LDS, 2 waves per SIMD)
     if (cout % 128 == 0) stagger(items, cus, (unsigned)P.NK * 900u + 1500u);
     dim3 grid((unsigned)((items < cus || !rec_persistent()) ? items : cus / 8 * 8)), block(512);
-    if (cout % 128 == 0) hipLaunchKernelGGL((k_conv3x3_rec<2, 2, 4>), grid, block, 0, s, P);
+    if (d_part) hipLaunchKernelGGL((k_conv3x3_rec_st<2, 2, 4>), grid, block, 0, s, P);
+    else if (cout % 128 == 0) hipLaunchKernelGGL((k_conv3x3_rec<2, 2, 4>), grid, block, 0, s, P);
     else hipLaunchKernelGGL((k_conv3x3_rec<1, 1, 2>), grid, block, 0, s, P);      // conv_out: one 32-cout tile, bias padded to 32 by the caller
     MDT_LAUNCH_CHECK();
     return MDTILE_OK;

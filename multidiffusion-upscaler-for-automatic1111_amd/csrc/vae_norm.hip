@@ -75,6 +75,31 @@ __global__ void k_gn_final(const double* __restrict__ part, size_t L, int BG, fl
     var[g] = (float)v;
 }
 
+// Statistics left by a conv's epilogue (k_conv3x3_bf16x3<.., ST = true> and the record kernels' epilogue_item<.., ST>): fp64 partials
+// part[b][unit][cb][QB quads][2] (unit = pixel tile of the producing kernel, cb = its cout block, quad = 4 consecutive couts).  Same
+// two-stage shape as k_gn_partial -> k_gn_final: GN_NBLK blocks per (sample, group) add their units in a fixed order.
+__global__ __launch_bounds__(256) void k_conv_stats_partial(const double* __restrict__ cpart, int units, int NCB, int QB, int cpg, int groups,
+                                                            double* __restrict__ part) {
+    __shared__ double sh[4];
+    const int bg = blockIdx.y, blk = blockIdx.x, b = bg / groups, g = bg - b * groups;
+    const int q_first = g * cpg / 4, nq = cpg / 4, cb = q_first / QB, q0 = q_first - cb * QB;
+    double s1 = 0.0, s2 = 0.0;
+    for (int u = blk * 256 + threadIdx.x; u < units; u += GN_NBLK * 256) {
+        const double2* p = reinterpret_cast<const double2*>(cpart) + (((size_t)b * units + u) * NCB + cb) * QB + q0;
+        for (int q = 0; q < nq; ++q) {
+            const double2 v = p[q];
+            s1 += v.x;
+            s2 += v.y;
+        }
+    }
+    s1 = block_sum_f64(s1, sh);
+    s2 = block_sum_f64(s2, sh);
+    if (threadIdx.x == 0) {
+        part[((size_t)bg * GN_NBLK + blk) * 2 + 0] = s1;
+        part[((size_t)bg * GN_NBLK + blk) * 2 + 1] = s2;
+    }
+}
+
 // Row-band variant for the sequence-parallel estimator: the (sample, group) covers `cpg` planes of `plane_stride` floats, of
 // which only [off, off + len) of every plane (this rank's own rows, halo rows excluded) enter the sums.  Output = the raw
 // fp64 (sum, sum of squares) per group: ranks all-reduce them and finish with k_gn_from_sums.
@@ -289,6 +314,22 @@ __global__ __launch_bounds__(256) void k_fast_apply(const float* __restrict__ z,
 }
 
 }  // namespace
+
+namespace mdt {
+// mean / var [B * groups] of a conv output [B, cout, H * W = HW] from the partials its epilogue left (d_cpart, see k_conv_stats_partial);
+// d_gnws: mdtile_gn_stats_ws_size(B, groups) bytes
+int conv_stats_finish_launch(const double* d_cpart, int B, int cout, size_t HW, int units, int NCB, int QB, int groups, float* d_mean, float* d_var,
+                             void* d_gnws, hipStream_t s) {
+    const int BG = B * groups, cpg = cout / groups;
+    MDT_CHECK_ARG(groups > 0 && cout % groups == 0 && cpg % 4 == 0 && (4 * QB) % cpg == 0 && BG <= 65535,
+                  "conv statistics: %d channels per group do not tile the kernel's %d-cout blocks in quads", cpg, 4 * QB);
+    hipLaunchKernelGGL(k_conv_stats_partial, dim3(GN_NBLK, BG), dim3(256), 0, s, d_cpart, units, NCB, QB, cpg, groups, (double*)d_gnws);
+    MDT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_gn_final, dim3(cdiv(BG, 128)), dim3(128), 0, s, (const double*)d_gnws, (size_t)cpg * HW, BG, d_mean, d_var);
+    MDT_LAUNCH_CHECK();
+    return MDTILE_OK;
+}
+}  // namespace mdt
 
 extern "C" size_t mdtile_gn_stats_ws_size(int B, int groups) { return (size_t)B * groups * GN_NBLK * 2 * sizeof(double); }
 

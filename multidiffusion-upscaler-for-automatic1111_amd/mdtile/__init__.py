@@ -121,6 +121,13 @@ _SIGNATURES = {
     "mdtile_conv2d_gn_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "mdtile_conv2d_gn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                  c_int, c_int, c_void_p]),
+    "mdtile_conv_stats_ws_size": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "mdtile_conv2d_gn_stats_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "mdtile_conv2d_gn_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                       c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mdtile_conv2d_rec_stats_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "mdtile_conv2d_rec_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                        c_void_p, c_void_p, c_void_p, c_void_p]),
     "mdtile_rec_size": (c_size_t, [c_int, c_int, c_int, c_int]),
     "mdtile_rec_from_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "mdtile_rec_to_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
@@ -765,15 +772,17 @@ class PackedConv:
 
     def call_rec(self, x: RecImage, residual: Optional[torch.Tensor] = None, upsample2x: bool = False, want_f32: bool = True,
                  want_rec: bool = False, rec_coef: Optional[torch.Tensor] = None, window: Optional[Tuple[int, int, int, int]] = None,
-                 family: int = 0):
-        """y = conv(x_rec) + bias (+ residual) -> (fp32 NCHW or None, RecImage or None).  The record output is
+                 family: int = 0, stats_groups: int = 0):
+        """y = conv(x_rec) + bias (+ residual) -> (fp32 NCHW or None, RecImage or None).
+        stats_groups = G (fp32 output only; leaves_stats(G, upsample2x, rec=True)): -> (y, None, (var, mean)) with get_var_mean of y from the
+        conv's own epilogue (mdtile_conv2d_rec_stats).  The record output is
         split(silu(a y + s)) with rec_coef = gn_coeffs(...) of the NEXT norm, or split(y) when rec_coef is None.
         window = (y0, x0, h, w) in INPUT pixels (upsample2x only; y0, x0: ints, or one int per image): the conv of that window of x,
         outputs [B, cout, 2h, 2w] (mdtile_upconv2d_rec_window: live-window narrowing of a decoder tile)."""
         B, cin, H, W = x.shape
         assert cin == self.cin and (want_f32 or want_rec)
         if window is not None:
-            assert upsample2x and residual is None, "a window is taken by the upsample conv only"
+            assert upsample2x and residual is None and not stats_groups, "a window is taken by the upsample conv only"
             y0, x0, h, w = window
             y0 = [int(y0)] * B if isinstance(y0, int) else [int(v) for v in y0]       # one origin for every image, or one per image
             x0 = [int(x0)] * B if isinstance(x0, int) else [int(v) for v in x0]
@@ -795,6 +804,13 @@ class PackedConv:
         if residual is not None:
             _dev_tensor(residual, "residual", torch.float32)
             assert tuple(residual.shape) == (B, self.cout, H, W)
+        if stats_groups:
+            assert want_f32 and not want_rec and rec_coef is None, "statistics come with the fp32 output only"
+            mean, var, ws = self._stats_buffers(B, H, W, int(stats_groups), x.data.device)
+            _check(lib().mdtile_conv2d_rec_stats(_p(x.data), _p(self.packed), _p(self.bias_rec), _p(residual), _p(y), B, self.cin, self.cout, H, W,
+                                                 (CONV_UPSAMPLE2X if upsample2x else 0) | int(family), int(stats_groups), _p(mean), _p(var), _p(ws),
+                                                 _stream()), "mdtile_conv2d_rec_stats")
+            return y, None, (var, mean)
         if rec_coef is not None:
             _dev_tensor(rec_coef, "rec_coef", torch.float32)
             assert want_rec and tuple(rec_coef.shape) == (B, 2, self.cout)
@@ -803,8 +819,20 @@ class PackedConv:
                "mdtile_conv2d_rec")
         return y, yr
 
+    def leaves_stats(self, groups: int = 32, upsample2x: bool = False, rec: bool = False) -> bool:
+        """True when this conv has a kernel whose epilogue also leaves the GroupNorm statistics of its output (slow mode: the producer of
+        a pooled norm's input): __call__(pre_gn=..., stats_groups=groups), or call_rec(..., stats_groups=groups) with rec=True."""
+        if rec:
+            return bool(lib().mdtile_conv2d_rec_stats_supported(self.cout, self.cin, self.ksize, CONV_UPSAMPLE2X if upsample2x else 0, int(groups)))
+        return bool(not upsample2x and lib().mdtile_conv2d_gn_stats_supported(self.cout, self.cin, self.ksize, 0, int(groups)))
+
+    def _stats_buffers(self, B: int, H: int, W: int, groups: int, device):
+        mean = torch.empty(B * groups, dtype=torch.float32, device=device)
+        ws = torch.empty((lib().mdtile_conv_stats_ws_size(B, self.cout, H, W, groups) + 7) // 8, dtype=torch.float64, device=device)
+        return mean, torch.empty_like(mean), ws
+
     def __call__(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, upsample2x: bool = False,
-                 token_major: bool = False, exact: bool = False, pre_gn: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 token_major: bool = False, exact: bool = False, pre_gn: Optional[torch.Tensor] = None, stats_groups: int = 0):
         """exact=True forces the exact-fp32 MFMA kernel; by default 3x3 convs with cin % 16 == 0 run on the split-bf16
         ("bf16x3") matrix-core kernel: fp32 accumulate, ~1e-5 relative to fp32.
         pre_gn = gn_coeffs(...) [B, 2, cin]: y = conv(silu(a * x + s)) -- GroupNorm + SiLU fused into the input staging
@@ -822,9 +850,16 @@ class PackedConv:
         if pre_gn is not None:
             _dev_tensor(pre_gn, "pre_gn", torch.float32)
             assert tuple(pre_gn.shape) == (B, 2, self.cin) and not token_major and not upsample2x
+            if stats_groups:
+                # -> (y, (var, mean)): get_var_mean of y from the conv's own epilogue (leaves_stats() says where)
+                mean, var, ws = self._stats_buffers(B, H, W, int(stats_groups), x.device)
+                _check(lib().mdtile_conv2d_gn_stats(_p(x), _p(pre_gn), _p(self.packed), _p(self.bias), _p(residual), _p(y), B, self.cin, self.cout,
+                                                    H, W, self.ksize, 0, int(stats_groups), _p(mean), _p(var), _p(ws), _stream()), "mdtile_conv2d_gn_stats")
+                return y, (var, mean)
             _check(lib().mdtile_conv2d_gn(_p(x), _p(pre_gn), _p(self.packed), _p(self.bias), _p(residual), _p(y), B, self.cin, self.cout,
                                           H, W, self.ksize, CONV_EXACT_F32 if exact else 0, _stream()), "mdtile_conv2d_gn")
             return y
+        assert not stats_groups, "statistics only from the kernels leaves_stats() names"
         _check(lib().mdtile_conv2d(_p(x), _p(self.packed), _p(self.bias), _p(residual), _p(y), B, self.cin, self.cout, H, W,
                                    self.ksize, (CONV_UPSAMPLE2X if upsample2x else 0) | (CONV_EXACT_F32 if exact else 0),
                                    int(token_major), _stream()), "mdtile_conv2d")

@@ -42,6 +42,9 @@ TILE_BATCH = int(_os.environ.get("MDTILE_TILE_BATCH", "4"))     # fast mode: til
 REC_PATH = _os.environ.get("MDTILE_REC", "1") != "0"
 # slow mode and the estimator pass: the record kernels at the pooled-statistics sites where they pay (VAEHook._pooled_site_takes_rec); 0 = fp32 hand-over
 SLOW_REC = _os.environ.get("MDTILE_SLOW_REC", "1") != "0"
+# slow mode: the conv that produces a pooled norm's input leaves that input's (var, mean) from its own epilogue where such a kernel exists
+# (PackedConv.leaves_stats); 0 = a statistics pass over every tile at every norm (A/B, debugging)
+SLOW_STATS = _os.environ.get("MDTILE_SLOW_STATS", "1") != "0"
 # fast-mode decoder tiles shed their dead border where the resolution doubles (live_windows below); 0 = decode the whole padded tile
 LIVE_WINDOW = _os.environ.get("MDTILE_LIVE_WINDOW", "1") != "0"
 # multi-GPU fast mode: run the GroupNorm estimator sequence-parallel across the ranks (mdtile/seqpar.py); 0 = every rank
@@ -237,8 +240,9 @@ class GroupNormParam:
         self.engine = engine or mdtile
         self.var_list, self.mean_list, self.pixel_list = [], [], []
 
-    def add_tile(self, tile: Tensor):
-        var, mean = self.engine.gn_stats(tile, 32)
+    def add_tile(self, tile: Tensor, stats=None):
+        """stats: (var, mean) of `tile` when its producer has already left them (TileState.stats); else one pass over the tile."""
+        var, mean = stats if stats is not None else self.engine.gn_stats(tile, 32)
         self.var_list.append(var)
         self.mean_list.append(mean)
         self.pixel_list.append(tile.shape[2] * tile.shape[3])
@@ -251,11 +255,12 @@ class GroupNormParam:
 
 # ---------------------------------------------------------------------------------------------------------------------
 class TileState:
-    __slots__ = ("x", "res", "pc", "pre")
+    __slots__ = ("x", "res", "pc", "pre", "stats")
 
     def __init__(self, x):
         self.x, self.res, self.pc = x, [], 0
         self.pre = None   # pending fused pre-activation: gn_coeffs of the norm just resolved, consumed by the next conv
+        self.stats = None  # slow mode: (var, mean) of x, left by the conv that produced it (None: nobody has them yet)
 
 
 class VAEHook:
@@ -317,17 +322,37 @@ class VAEHook:
             self._program_dev = dev
         return self._program
 
-    def _run_until_norm(self, steps: List[Step], st: TileState):
-        """Advance one tile to its next GroupNorm (exclusive) or to the end."""
+    @staticmethod
+    def _feeds_norm(steps: List[Step], i: int) -> bool:
+        """The value steps[i] produces is the input of a GroupNorm (only residual bookkeeping in between)."""
+        j = i + 1
+        while j < len(steps) and steps[j].kind == "store_res":
+            j += 1
+        return j < len(steps) and steps[j].kind == "norm"
+
+    def _run_until_norm(self, steps: List[Step], st: TileState, want_stats: bool = False):
+        """Advance one tile to its next GroupNorm (exclusive) or to the end.
+        want_stats (slow mode, the norm ahead is pooled): the conv that produces the norm's input also leaves its (var, mean) in st.stats
+        where a kernel does that in its epilogue (PackedConv.leaves_stats) -- GroupNormParam.add_tile then needs no pass over the tile."""
+        want_stats = want_stats and SLOW_STATS
         while st.pc < len(steps):
             s = steps[st.pc]
             if s.kind == "norm":
                 return
+            if s.kind != "store_res":
+                st.stats = None
             if s.kind == "store_res":
                 st.res.append(st.x if s.conv is None else s.conv(st.x))
             elif s.kind == "conv":
+                stats_fn = getattr(s.conv, "leaves_stats", None) if want_stats and self._feeds_norm(steps, st.pc) else None
                 if s.downsample:
                     st.x = s.conv.down2(st.x)
+                elif stats_fn is not None and self._pooled_site_takes_rec(s) and stats_fn(32, upsample2x=s.upsample, rec=True):
+                    xrec = self.engine.rec_from_f32(st.x, st.pre)
+                    st.x, _, st.stats = s.conv.call_rec(xrec, residual=st.res.pop() if s.fuse_res else None, upsample2x=s.upsample, want_f32=True,
+                                                        want_rec=False, stats_groups=32)
+                elif stats_fn is not None and st.pre is not None and not s.upsample and not self._pooled_site_takes_rec(s) and stats_fn(32):
+                    st.x, st.stats = s.conv(st.x, residual=st.res.pop() if s.fuse_res else None, pre_gn=st.pre, stats_groups=32)
                 elif self._pooled_site_takes_rec(s):
                     # pooled-statistics site on the record kernels: one conversion pass (norm + SiLU fused into it) + the record conv --
                     # the fp32 hand-over kernel's output to fp32 rounding (a fused residual enters the accumulation first here: (res + sum) + bias), cheaper where _pooled_site_takes_rec says so
@@ -789,9 +814,9 @@ class VAEHook:
                     if state.interrupted:
                         interrupted = True
                         break
-                    self._run_until_norm(steps, tiles[i])
+                    self._run_until_norm(steps, tiles[i], want_stats=not use_frozen)
                     if tiles[i].pc < len(steps) and not use_frozen:
-                        gp.add_tile(tiles[i].x)
+                        gp.add_tile(tiles[i].x, tiles[i].stats)
                 if interrupted and world == 1:
                     break
                 # several ranks: an interrupted rank runs no more tiles but keeps walking the norms to the next POOLED barrier, where the

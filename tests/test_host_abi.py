@@ -91,7 +91,7 @@ def test_dma_protocol_in_the_device_assembly():
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asm_guard.py")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout
-    assert r.stdout.count(" ok") == 11, r.stdout      # 2 streaming 1x1 + 3 record (one block per CU) + 2 record (two blocks per CU) + 1 record (dripped epilogue) + 3 attention
+    assert r.stdout.count(" ok") == 13, r.stdout      # 2 streaming 1x1 + 3 record (one block per CU) + 2 of them with statistics + 2 record (two blocks per CU) + 1 record (dripped epilogue) + 3 attention
 
 
 def test_environment_switches_of_the_shipping_library(built_lib):
@@ -111,7 +111,7 @@ def test_environment_switches_of_the_shipping_library(built_lib):
             if re.search(r"\bgetenv\(", line) and "probe_env" not in line:
                 getenv_sites.append((f, re.findall(r'"(MDTILE_[A-Z0-9_]+)"', line)))
     assert sorted(n for _, names in getenv_sites for n in names) == ["MDTILE_ATTN_MODE", "MDTILE_CONV_MODE", "MDTILE_SHARD_TRANSPORT"], getenv_sites
-    allowed_py = {"MDTILE_LIVE_WINDOW", "MDTILE_TILE_BATCH", "MDTILE_SP_ESTIMATOR", "MDTILE_SLOW_REC", "MDTILE_REC", "MDTILE_FUSE_GN",
+    allowed_py = {"MDTILE_LIVE_WINDOW", "MDTILE_TILE_BATCH", "MDTILE_SP_ESTIMATOR", "MDTILE_SLOW_REC", "MDTILE_SLOW_STATS", "MDTILE_REC", "MDTILE_FUSE_GN",
                   "MDTILE_SHARD_PROBE", "MDTILE_SHARD_TORCH", "MDTILE_SKIP_ASM_GUARD"}
     plug = os.path.join(ROOT, "multidiffusion-upscaler-for-automatic1111_amd")
     seen = set()

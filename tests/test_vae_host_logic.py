@@ -162,11 +162,11 @@ def _worker_interrupt(rank, world, port, q):
         calls = [0]
         orig = hook._run_until_norm
 
-        def counted(steps, st):
+        def counted(steps, st, **kw):
             calls[0] += 1
             if rank == 1 and calls[0] == 3:
                 state.interrupted = True
-            return orig(steps, st)
+            return orig(steps, st, **kw)
 
         hook._run_until_norm = counted
         with torch.no_grad():
@@ -238,6 +238,40 @@ def test_pooled_statistics_sites_take_the_record_kernels_where_they_pay(monkeypa
     assert torch.allclose(outs[True], outs[False], rtol=0, atol=1e-5 * outs[False].abs().max().item())
     with torch.no_grad():
         ref = vo.tiled_forward(ld.make_decoder(0, small=True), z, 16, fast)
+    assert (outs[True] - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("rec_convs", [True, False], ids=["record_doubles", "handover_doubles"])
+def test_slow_mode_takes_the_statistics_the_producing_conv_leaves(monkeypatch, rec_convs):
+    """Slow mode (scripts/tilevae.py lockstep loop, upstream :289-361): where the conv that produces a pooled norm's input can leave the
+    statistics of its output (PackedConv.leaves_stats -> TileState.stats), GroupNormParam.add_tile takes them instead of a pass over the
+    tile (engine.gn_stats).  Same image as with MDTILE_SLOW_STATS=0, same as the oracle; the passes that remain are the ones whose input
+    no 3x3 conv with a fused pre-activation produces (conv_in, the attention block's output)."""
+    from hostsim import ldm_decoder as ld
+    from oracle import vae_oracle as vo
+    import torch_engine as te
+    torch.manual_seed(9)
+    z = torch.randn(1, 4, 36, 44)
+    outs, passes, left = {}, {}, {}
+    for on in (True, False):
+        hook = _rec_hook(ld.make_decoder(0, small=True), 16, fast=False, rec_convs=rec_convs)
+        pl = sys.modules[type(hook).__module__]
+        monkeypatch.setattr(pl, "SLOW_STATS", on)
+        calls = []
+        orig = hook.engine.gn_stats
+        hook.engine.gn_stats = lambda x, g=32: (calls.append(tuple(x.shape)), orig(x, g))[1]
+        te.TorchConv.stats_left = 0
+        with torch.no_grad():
+            outs[on] = hook(z)
+        passes[on], left[on] = len(calls), te.TorchConv.stats_left
+    n_tiles = len(vo.split_tiles(36, 44, 16)[0])
+    assert left[False] == 0 and left[True] > 0
+    assert passes[True] + left[True] == passes[False]              # every (tile, norm) statistic comes from exactly one of the two
+    # what is left per tile: conv_in's output and the attention block's (+ the three upsample convs' where only the record kernels leave them)
+    assert passes[True] == (2 if rec_convs else 5) * n_tiles and passes[False] == 30 * n_tiles, (passes, n_tiles)
+    assert torch.equal(outs[True], outs[False])                    # (the doubles compute both forms with the same torch call)
+    with torch.no_grad():
+        ref = vo.tiled_forward(ld.make_decoder(0, small=True), z, 16, False)
     assert (outs[True] - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
 
 

@@ -25,7 +25,14 @@ class TorchConv:
     def fuses_pre_gn(self, upsample2x=False, token_major=False, exact=False):
         return self.ksize == 3 and not self.down and not upsample2x and not token_major and self.cin % 16 == 0 and self.cout >= 32
 
-    def __call__(self, x, residual=None, upsample2x=False, token_major=False, exact=False, pre_gn=None):
+    stats_left = 0       # calls that also left the statistics of their output (mdtile_conv2d_gn_stats / _rec_stats stand-ins)
+
+    def leaves_stats(self, groups=32, upsample2x=False, rec=False):
+        """PackedConv.leaves_stats: the stand-in says yes wherever the product's 128-cout kernels could (whole quads per group), scaled to the
+        small test decoders: couts in whole groups of >= 1."""
+        return self.ksize == 3 and not self.down and self.cout % groups == 0 and (rec or not upsample2x)
+
+    def __call__(self, x, residual=None, upsample2x=False, token_major=False, exact=False, pre_gn=None, stats_groups=0):
         if pre_gn is not None:
             x = F.silu(x * pre_gn[:, 0, :, None, None] + pre_gn[:, 1, :, None, None])
         if upsample2x:
@@ -36,6 +43,10 @@ class TorchConv:
         if token_major:
             B, C, H, W = y.shape
             y = y.permute(0, 2, 3, 1).reshape(B, H * W, C).contiguous()
+        if stats_groups:
+            assert pre_gn is not None and not token_major
+            TorchConv.stats_left += 1
+            return y, vo.get_var_mean(y, stats_groups)
         return y
 
     def down2(self, x):
@@ -159,7 +170,7 @@ class TorchConvRec(TorchConv):
     def takes_rec(self, upsample2x=False):
         return self.ksize == 3 and not self.down and self.cin % 32 == 0 and self.cout % 32 == 0
 
-    def call_rec(self, xrec, residual=None, upsample2x=False, want_f32=True, want_rec=False, rec_coef=None, window=None):
+    def call_rec(self, xrec, residual=None, upsample2x=False, want_f32=True, want_rec=False, rec_coef=None, window=None, stats_groups=0):
         x = xrec.t
         if window is not None:
             # mdtile_upconv2d_rec_window: the conv of a window of the input whose edges inside the image see the true neighbours ==
@@ -185,17 +196,21 @@ class TorchConvRec(TorchConv):
         yr = None
         if want_rec:
             yr = TorchRec(F.silu(y * rec_coef[:, 0, :, None, None] + rec_coef[:, 1, :, None, None]) if rec_coef is not None else y)
+        if stats_groups:
+            assert want_f32 and not want_rec and window is None
+            TorchConv.stats_left += 1
+            return y, None, vo.get_var_mean(y, stats_groups)
         return (y if want_f32 else None), yr
 
 
 class TorchConvCounting(TorchConv):
     """TorchConv (no record form) that books its output elements in the same counter as TorchConvRec."""
 
-    def __call__(self, x, residual=None, upsample2x=False, token_major=False, exact=False, pre_gn=None):
-        y = super().__call__(x, residual, upsample2x, token_major, exact, pre_gn)
+    def __call__(self, x, residual=None, upsample2x=False, token_major=False, exact=False, pre_gn=None, stats_groups=0):
+        out = super().__call__(x, residual, upsample2x, token_major, exact, pre_gn, stats_groups)
         if self.ksize == 3:
-            TorchConvRec.px_computed += y.numel()
-        return y
+            TorchConvRec.px_computed += (out[0] if stats_groups else out).numel()
+        return out
 
 
 class TorchEngineRec(TorchEngine):

@@ -126,6 +126,9 @@ def main() -> int:
         (rec, "k_conv3x3_recILi2ELi2ELi4", dict(dma_min=8, barrier_vmcnt=[0, 5], mfma_multiple=12)),
         (rec, "k_conv3x3_recILi1ELi1ELi2", dict(dma_min=4, barrier_vmcnt=[0, 5], mfma_multiple=3)),
         (rec, "k_upconv_recE", dict(dma_min=8, barrier_vmcnt=[0], mfma_multiple=12)),
+        # the same two kernel texts + statistics in the epilogue (slow mode's pooled sites): the protocol is the shipping kernels'
+        (rec, "k_conv3x3_rec_stILi2ELi2ELi4", dict(dma_min=8, barrier_vmcnt=[0, 5], mfma_multiple=12)),
+        (rec, "k_upconv_rec_stE", dict(dma_min=8, barrier_vmcnt=[0], mfma_multiple=12)),
         # two blocks per CU: one counted wait per step position (tools/rec2_protocol_sim.py derives and checks the values)
         (rec2, "k_conv3x3_rec2ILi2ELi2ELi4", dict(dma_min=8, barrier_vmcnt=[0, 2, 3, 4], mfma_multiple=12)),
         (rec2, "k_upconv_rec2E", dict(dma_min=8, barrier_vmcnt=[0, 6, 7, 8, 9], mfma_multiple=12)),
