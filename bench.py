@@ -160,7 +160,8 @@ def run_encode(args, E, pl, ld, dev):
         flops = 2.0 * B * H * W * self.cout * cin * self.ksize * self.ksize
         bf = bfx and not exact and not token_major and cin % 16 == 0
         tag = ("k_conv1x1_stream<*> / k_conv1x1_bf16x3<*>" if (bf and cin % 32 == 0) else "k_conv<1,*> (exact fp32 MFMA)") if self.ksize == 1 else \
-              ("k_conv3x3_bf16x3<*> (fp32 hand-over)" if bf else "k_conv<3,*> (exact fp32 MFMA)")
+              ("k_conv3x3_bf16x3<*> (fp32 hand-over)" if bf else "k_conv3x3_fewcin<*> (conv_in, fp32 FMA)" if cin in (3, 4) and not upsample2x and not token_major
+               else "k_conv<3,*> (exact fp32 MFMA)")
         return prof.wrap(tag, flops, lambda: orig_call(self, xx, residual, upsample2x, token_major, exact, pre_gn, **kw))
 
     def timed_down(self, xx):
@@ -468,7 +469,8 @@ def main():
                     flops *= 4.0 / 9.0      # sub-pixel form of nearest-2x + 3x3 conv: four 2x2 convs -> 4/9 of the MACs are EXECUTED
                     tag = "k_upconv_bf16x3<*> (fp32 hand-over)"
                 else:
-                    tag = "k_conv3x3_bf16x3<*> (fp32 hand-over)" if bf else "k_conv<3,*> (exact fp32 MFMA)"
+                    tag = "k_conv3x3_bf16x3<*> (fp32 hand-over)" if bf else "k_conv3x3_fewcin<*> (conv_in, fp32 FMA)" if cin in (3, 4) and not token_major \
+                        else "k_conv<3,*> (exact fp32 MFMA)"
                 return prof.wrap(tag, flops, lambda: orig_call(self, x, residual, upsample2x, token_major, exact, pre_gn, **kw))
 
             def timed_rec(self, x, residual=None, upsample2x=False, want_f32=True, want_rec=False, rec_coef=None, window=None, family=0, **kw):

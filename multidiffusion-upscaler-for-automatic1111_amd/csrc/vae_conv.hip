@@ -198,6 +198,83 @@ __global__ void k_conv_pack(const float* __restrict__ w, float* __restrict__ wp,
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// ---- conv_in (round 5): 3x3 convs with 3 or 4 input channels (the encoder's first conv 3 -> 128 on the IMAGE tile, the decoder's 4 -> 512 on the
+// latent tile; scripts/tilevae.py:115-137 'conv_in').  K = 27 / 36 leaves the matrix cores nothing to do -- the MFMA kernel above ran it at
+// 14 TFLOP/s, 4.3 ms per 3072^2 encoder tile -- and the op is its OUTPUT stream: 128 planes x 4 B per pixel.  Plain fp32 FMAs (exact fp32 in
+// every precision mode): a lane owns two adjacent pixels of a row as packed pairs (v_pk_fma_f32), its 4 x 3 x CIN input values live in
+// registers, the weights of 128 couts sit in LDS [cout][tap][cin] and are read as wave-wide broadcasts (16 B per read, no conflicts);
+// one 8-byte store per cout and lane = 512-byte runs per wave.  Block = 4 waves = 4 rows x 128 px x 128 couts.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int CIN>
+__global__ __launch_bounds__(256) void k_conv3x3_fewcin(const float* __restrict__ x, const float* __restrict__ wpk, const float* __restrict__ bias,
+                                                        const float* __restrict__ res, float* __restrict__ y, int Cout, int CoutP, int NCB, int H, int W) {
+    constexpr int K = 9 * CIN, KP = (K + 3) & ~3;
+    __shared__ float4 wl4[128 * KP / 4];
+    float* const wl = reinterpret_cast<float*>(wl4);
+    const int cb = blockIdx.z % NCB, b = blockIdx.z / NCB;
+    for (int i = threadIdx.x; i < 128 * KP; i += 256) {       // packed fp32 image [tap][cin][CoutP] -> LDS [cout][tap * CIN + cin]
+        const int co = i & 127, k = i >> 7;
+        wl[co * KP + k] = (k < K && cb * 128 + co < Cout) ? wpk[(size_t)k * CoutP + cb * 128 + co] : 0.0f;
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int yy = blockIdx.y * 4 + wave, x0 = blockIdx.x * 128 + lane * 2;
+    if (yy >= H || x0 >= W) return;
+    const size_t HW = (size_t)H * W;
+    const float* xb = x + (size_t)b * CIN * HW;
+    f32x2 in[KP];      // in[tap * CIN + ci] = (pixel x0, pixel x0 + 1) under tap (dy, dx): input columns x0 + dx - 1, x0 + dx
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int r = yy + dy - 1;
+            float v[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int xc = x0 + c - 1;
+                v[c] = (r >= 0 && r < H && xc >= 0 && xc < W) ? xb[(size_t)ci * HW + (size_t)r * W + xc] : 0.0f;      // 'same' zero padding
+            }
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) in[(dy * 3 + dx) * CIN + ci] = f32x2{v[dx], v[dx + 1]};
+        }
+#pragma unroll
+    for (int k = K; k < KP; ++k) in[k] = f32x2{0.0f, 0.0f};
+    const bool two = x0 + 1 < W;
+    const size_t o0 = (size_t)yy * W + x0;
+    const bool pair_ok = two && ((o0 & 1) == 0) && ((HW & 1) == 0);      // 8-byte aligned in every plane
+    const int nco = Cout - cb * 128 < 128 ? Cout - cb * 128 : 128;
+    float* yb = y + ((size_t)b * Cout + cb * 128) * HW + o0;
+    const float* rb = res ? res + ((size_t)b * Cout + cb * 128) * HW + o0 : nullptr;
+#pragma unroll 4
+    for (int co = 0; co < nco; ++co) {      // (four couts in flight: independent FMA chains)
+        const float bv = bias ? bias[cb * 128 + co] : 0.0f;
+        f32x2 acc = f32x2{0.0f, 0.0f};
+        const float4* wr = wl4 + co * (KP / 4);
+#pragma unroll
+        for (int k4 = 0; k4 < KP / 4; ++k4) {
+            const float4 w = wr[k4];
+            acc = __builtin_elementwise_fma(in[4 * k4 + 0], f32x2{w.x, w.x}, acc);
+            acc = __builtin_elementwise_fma(in[4 * k4 + 1], f32x2{w.y, w.y}, acc);
+            acc = __builtin_elementwise_fma(in[4 * k4 + 2], f32x2{w.z, w.z}, acc);
+            acc = __builtin_elementwise_fma(in[4 * k4 + 3], f32x2{w.w, w.w}, acc);
+        }
+        acc += f32x2{bv, bv};
+        float* yp = yb + (size_t)co * HW;
+        if (rb) {
+            acc.x += rb[(size_t)co * HW];
+            if (two) acc.y += rb[(size_t)co * HW + 1];
+        }
+        if (pair_ok) {
+            *reinterpret_cast<f32x2*>(yp) = acc;
+        } else {
+            yp[0] = acc.x;
+            if (two) yp[1] = acc.y;
+        }
+    }
+}
+
+static bool conv_fewcin_eligible(int cin, int ksize, int up, int out_layout) { return ksize == 3 && (cin == 3 || cin == 4) && !up && out_layout == 0; }
+
 template <int KS, int KC, int WP, int WC, int RP, int RC>
 int launch_conv(ConvParams& P, int out_layout, hipStream_t s) {
     constexpr int BN = WC * RC * 32;
@@ -309,6 +386,15 @@ extern "C" int mdtile_conv2d(const float* d_x, const float* d_w_packed, const fl
     if (ksize == 1 && !up && !force_f32 && !(flags & MDTILE_CONV_EXACT_F32) && out_layout == 0 && conv1x1_bf16x3_eligible(cout, cin))
         return conv1x1_bf16x3_launch(d_x, d_w_packed + f32_packed_floats(cout, cin, ksize), d_bias, d_residual, d_y, B, cin, cout,
                                      (size_t)H * W, s);
+    if (conv_fewcin_eligible(cin, ksize, up, out_layout)) {      // conv_in: exact fp32 FMAs, bound by its output stream (every precision mode)
+        const int ncb = (cout + 127) / 128;
+        MDT_CHECK_ARG((size_t)B * ncb <= 65535 && (H + 3) / 4 <= 65535, "mdtile_conv2d: conv_in grid too large (B=%d cout=%d H=%d)", B, cout, H);
+        dim3 grid((W + 127) / 128, (H + 3) / 4, B * ncb), block(256);
+        if (cin == 3) hipLaunchKernelGGL(k_conv3x3_fewcin<3>, grid, block, 0, s, d_x, d_w_packed, d_bias, d_residual, d_y, cout, P.CoutP, ncb, H, W);
+        else hipLaunchKernelGGL(k_conv3x3_fewcin<4>, grid, block, 0, s, d_x, d_w_packed, d_bias, d_residual, d_y, cout, P.CoutP, ncb, H, W);
+        MDT_LAUNCH_CHECK();
+        return MDTILE_OK;
+    }
     const bool wide = P.CoutP > 64;
     if (ksize == 3) {
         if (wide) return launch_conv<3, 8, 2, 2, 4, 2>(P, out_layout, s);

@@ -540,10 +540,11 @@ class VAEHook:
             first_down = next((i for i, s in enumerate(steps) if s.kind == "conv" and s.downsample), len(steps))
             n_norm = sum(1 for s in steps[:first_down] if s.kind == "norm")
         while True:
-            self._run_until_norm(steps, st)
+            self._run_until_norm(steps, st, want_stats=True)
             if st.pc >= len(steps):
                 break
-            var, mean = self.engine.gn_stats(st.x, 32)
+            # (the conv that produced st.x has left its statistics where a kernel does that in its epilogue: TileState.stats)
+            var, mean = st.stats if st.stats is not None else self.engine.gn_stats(st.x, 32)
             frozen.append((var, mean))
             if len(frozen) == n_norm:
                 break

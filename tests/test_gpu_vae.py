@@ -91,6 +91,11 @@ CONV_CASES = [  # B, cin, cout, k, H, W, upsample, residual, token_major
     (1, 512, 128, 1, 64, 64, False, False, False),   # streaming 1x1: 32 K-steps
     (1, 64, 512, 1, 40, 64, False, True, False),     # streaming 1x1, 256-cout blocks x 2, residual
     (1, 64, 128, 1, 45, 47, False, True, False),     # H*W % 4 != 0: stays on the plain 1x1 kernel
+    (1, 3, 128, 3, 37, 131, False, False, False),    # conv_in kernel (k_conv3x3_fewcin): the encoder's 3 -> 128, odd width (unpaired last pixel, odd plane size)
+    (2, 4, 512, 3, 19, 260, False, True, False),     # conv_in kernel: the decoder's 4 -> 512 (four cout blocks), three column blocks, batch, residual
+    (1, 3, 48, 3, 5, 2, False, False, False),        # conv_in kernel: fewer couts than a block, a 2-px-wide image
+    (1, 4, 128, 3, 1, 1, False, False, False),       # conv_in kernel: one pixel
+    (1, 3, 128, 3, 64, 129, False, True, False),     # conv_in kernel: odd row pitch (pairs only 8-byte aligned on every other row)
 ]
 
 
