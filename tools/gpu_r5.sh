@@ -5,6 +5,7 @@
 #   encode   bench.py --encode (the ENCODE companion line)
 #   stress   tests/test_gpu_vae_stress.py -s (the numbers it prints)
 #   micro    probes/simd_map_probe + probes/mfma_valu_overlap_probe
+#   slow     bench.py --slow-vae with the statistics from the conv epilogues and (MDTILE_SLOW_STATS=0) with a statistics pass per norm, twice each
 TAG=${1:-r5}; shift
 WHAT=${*:-"tests smoke bench"}
 mkdir -p gpurun_out
@@ -23,6 +24,9 @@ for w in $WHAT; do
         cat $O/conv_drip_ab_$TAG.log;;
     encode) (timeout 900 python bench.py --encode --steps 2 --warmup 1 2>&1 | tail -1) > $O/bench_encode_$TAG.json 2>&1; cut -c1-3000 $O/bench_encode_$TAG.json;;
     stress) (timeout 900 python -m pytest tests/test_gpu_vae_stress.py -m gpu -q -s -p no:cacheprovider 2>&1 | grep "stress\|attention at\|passed\|failed") > $O/pytest_stress_$TAG.log 2>&1; cat $O/pytest_stress_$TAG.log;;
+    slow) : > $O/slow_ab_$TAG.log
+        for v in 1 0 1 0; do MDTILE_SLOW_STATS=$v timeout 600 python bench.py --slow-vae --steps 2 --warmup 1 --no-oracle-pass --no-stress-pass --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys, json; d = json.loads(sys.stdin.read()); print('MDTILE_SLOW_STATS=$v  slow-mode 8K step', d['ms_per_step'], 'ms')" >> $O/slow_ab_$TAG.log 2>&1; done
+        cat $O/slow_ab_$TAG.log;;
     micro) (probes/simd_map_probe; probes/mfma_valu_overlap_probe) > $O/micro_$TAG.log 2>&1; cat $O/micro_$TAG.log;;
     *) bash $R/tools/gpu_r3.sh $TAG $w;;
   esac
