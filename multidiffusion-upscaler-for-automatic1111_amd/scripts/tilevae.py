@@ -371,11 +371,14 @@ class VAEHook:
         """Slow mode / the estimator pass: a norm whose statistics are pooled cannot be applied by the conv that PRODUCES its input, so the
         record kernels cost an extra conversion pass (fp32 -> activated records) there.  They still win where the conv is long against its
         activation: the 512 -> 512 layers (-7 ... -9 % incl. the pass) and every upsample conv (the pass runs on the quarter-size input:
-        -8 ... -21 %); at 256 / 128 input channels the pass costs more than the faster conv saves (+1 ... +8 %) -- profiles/r4z/conv_probe.log."""
+        -8 ... -21 %); at 256 / 128 input channels the pass costs more than the faster conv saves (+1 ... +8 %) -- profiles/r4z/conv_probe.log.
+        conv_out (cout < 32) behind a pooled norm_out: no hand-over kernel applies a norm for so few couts, so the alternative is a norm pass
+        (1R + 1W) + the exact-fp32 conv -- 3.8 ms per 2224^2 tile against 1.9 ms for conversion pass + narrow record conv (profiles/r5q:
+        kernel_stats_slow.csv, 61 ms of a slow-mode 8K decode)."""
         if not (SLOW_REC and REC_PATH and hasattr(self.engine, "rec_from_f32") and self._takes_rec(s)):
             return False
         c = s.conv
-        return bool(s.upsample or (getattr(c, "cin", 0) >= 512 and getattr(c, "cout", 0) >= 512))
+        return bool(s.upsample or (getattr(c, "cin", 0) >= 512 and getattr(c, "cout", 0) >= 512) or 0 < getattr(c, "cout", 0) < 32)
 
     def _tile_batch_that_fits(self, N: int, tile_hw: Tuple[int, int], dev) -> int:
         """Tiles of one shape per sweep (TILE_BATCH at most): what 60 % of the free device memory holds.  Peak of one tile: about five
@@ -519,7 +522,7 @@ class VAEHook:
         gamma, beta = s.norm
         nxt = steps[st.pc + 1] if st.pc + 1 < len(steps) else None
         if (FUSE_PRE_GN and s.silu and nxt is not None and nxt.kind == "conv" and not nxt.downsample
-                and nxt.conv.fuses_pre_gn(upsample2x=nxt.upsample)):
+                and (nxt.conv.fuses_pre_gn(upsample2x=nxt.upsample) or (not nxt.upsample and self._pooled_site_takes_rec(nxt)))):
             # norm + SiLU ride on the conv's input staging: only the per-channel (a, s) pair is formed here
             st.pre = E.gn_coeffs(mean, var, gamma, beta, st.x.shape[1], 32, 1e-6)
         else:

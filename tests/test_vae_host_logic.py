@@ -234,6 +234,7 @@ def test_pooled_statistics_sites_take_the_record_kernels_where_they_pay(monkeypa
         mk = lambda cin, cout, up: pl.Step("conv", conv=type("C", (), {"cin": cin, "cout": cout, "takes_rec": lambda self, u=False: True})(), upsample=up)
         assert hook._pooled_site_takes_rec(mk(256, 256, True)) == on and hook._pooled_site_takes_rec(mk(512, 512, False)) == on
         assert not hook._pooled_site_takes_rec(mk(256, 256, False)) and not hook._pooled_site_takes_rec(mk(512, 256, False))
+        assert hook._pooled_site_takes_rec(mk(128, 3, False)) == on      # conv_out behind a pooled norm_out: conversion pass + narrow record conv
     assert used[True] > 0 and used[False] == 0              # the small decoder has no 512-channel layer: its three upsample convs per pass
     assert torch.allclose(outs[True], outs[False], rtol=0, atol=1e-5 * outs[False].abs().max().item())
     with torch.no_grad():

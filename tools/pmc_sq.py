@@ -43,8 +43,15 @@ def main():
                 if c in e:
                     e[nm] = e[c] / e["SQ_WAVE_CYCLES"]
         res[k[:150]] = e
+    digest = None
+    try:      # source digest of the library the counted process loaded (the same tree: gpurun snapshots it), as tools/pmc_summary.py records it
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "multidiffusion-upscaler-for-automatic1111_amd"))
+        from mdtile import build
+        digest = build._digest()[:12]
+    except Exception:
+        pass
     with open(out, "w") as f:
-        json.dump({"kernels": res}, f, indent=1)
+        json.dump({"libmdtile_digest": digest, "kernels": res}, f, indent=1)
     for k, e in sorted(res.items(), key=lambda kv: -kv[1].get("avg_ns", 0))[:8]:
         print(k[:70], {a: (round(b, 3) if isinstance(b, float) and b < 100 else b) for a, b in e.items() if a in (
             "dispatches", "avg_ns", "mfma_busy_frac_at_2.4GHz", "clock_GHz", "mfma_busy_frac_at_clock", "wave_parked_frac", "wave_issue_stall_frac", "wave_issuing_frac")})
