@@ -307,7 +307,6 @@ int mdtile_conv2d_gn_stats(const float* d_x, const float* d_coef, const float* d
  *                                (ldm Upsample, tilevae.py:139-153).  H, W = output size.  d_w_packed: mdtile_conv_pack(ksize 3). */
 #define MDTILE_CONV_REC_ONE_BLOCK 4   /* mdtile_conv2d_rec / mdtile_upconv2d_rec_window flags: name the kernel family instead of letting the */
 #define MDTILE_CONV_REC_TWO_BLOCKS 8  /* launcher choose per launch (one 8-wave block per CU / two 4-wave blocks per CU; identical results) */
-#define MDTILE_CONV_REC_DRIP 16       /* ... / 64-cout items whose epilogue is dripped into the next item's K loop (direct 3x3, cin % 128 == 0) */
 size_t mdtile_rec_size(int B, int C, int H, int W);
 int mdtile_rec_from_f32(const float* d_x, const float* d_coef, void* d_rec, int B, int C, int H, int W, mdtile_stream_t stream);
 int mdtile_rec_to_f32(const void* d_rec, float* d_x, int B, int C, int H, int W, mdtile_stream_t stream);

@@ -490,7 +490,8 @@ extern "C" int mdtile_conv2d_rec_supported(int cout, int cin, int ksize, int fla
 }
 
 // MDTILE_CONV_REC_ONE_BLOCK / _TWO_BLOCKS: the caller names the kernel family (tests, probes); 0 = chosen per launch (rec_two_blocks)
-static int rec_family(int flags) { return (flags & MDTILE_CONV_REC_ONE_BLOCK) ? 1 : (flags & MDTILE_CONV_REC_TWO_BLOCKS) ? 2 : (flags & MDTILE_CONV_REC_DRIP) ? 3 : 0; }
+// (bit 16 names the dripped-epilogue probe kernel, in the PROBES twin of the library only: probes/csrc/vae_conv_recd.hip)
+static int rec_family(int flags) { return (flags & MDTILE_CONV_REC_ONE_BLOCK) ? 1 : (flags & MDTILE_CONV_REC_TWO_BLOCKS) ? 2 : (kProbes && (flags & 16)) ? 3 : 0; }
 
 extern "C" int mdtile_conv2d_rec(const void* d_x_rec, const float* d_w_packed, const float* d_bias, const float* d_residual, float* d_y,
                                  void* d_y_rec, const float* d_y_coef, int B, int cin, int cout, int H, int W, int flags,

@@ -174,7 +174,9 @@ static int num_cus() {
 
 // vae_conv_rec2.hip: the two-blocks-per-CU form of the cout % 128 == 0 kernels
 int conv_rec2_launch(ConvRParams P, int B, int up, hipStream_t s, int cus);
-// vae_conv_recd.hip: 64-cout items with the epilogue dripped into the next item's K loop (direct 3x3, cin % 128 == 0)
+// probes/csrc/vae_conv_recd.hip (PROBES twin of the library only -- a measured, rejected form: DESIGN.md / docs/history/r5.md): 64-cout items with
+// the epilogue dripped into the next item's K loop (direct 3x3, cin % 32 == 0, cin >= 128).  Declared here, defined only in that build: the one
+// call sits in a discarded `if constexpr (kProbes)` statement, so the shipping library neither references nor carries the kernel.
 bool conv_recd_supported(int cout, int cin);
 int conv_recd_launch(ConvRParams P, int B, hipStream_t s, int cus);
 
@@ -265,7 +267,13 @@ int conv_rec_launch(const void* d_xrec, const void* d_w_rec, const float* d_bias
     if (P.dbg & 8)
         if (const char* e = probe_env("MDTILE_REC_STAMPS")) P.census = reinterpret_cast<unsigned*>((uintptr_t)strtoull(e, nullptr, 16));
     if (up) P.w = (const u32x4*)d_w_rec + conv_bf16x3_direct_records(cout, cin);
-    if (family == 3 && !up && conv_recd_supported(cout, cin)) return conv_recd_launch(P, B, s, num_cus());
+    if constexpr (kProbes) {
+        if (family == 3) {      // a NAMED family is honoured or refused, never silently replaced by the cost model
+            MDT_CHECK_ARG(!up && !win && !d_part && conv_recd_supported(cout, cin), "conv_rec_launch: the dripped-epilogue kernel takes direct 3x3 convs with cin %% 32 == 0, "
+                          "cin >= 128, cout %% 128 == 0, no window, no statistics (cout=%d cin=%d up=%d)", cout, cin, up);
+            return conv_recd_launch(P, B, s, num_cus());
+        }
+    }
     if (cout % 128 == 0 && rec_persistent()) {
         const int cus = num_cus() / 8 * 8;
         const int hin = up ? P.Hin : H, win = up ? P.Win : W, per = P.NCB * (up ? 2 : 1);      // items tile the INPUT grid of the sub-pixel form

@@ -601,7 +601,10 @@ __global__ __launch_bounds__(256, 2) void k_upconv_rec2(const ConvRParams P) {
 namespace mdt {
 
 // arrival counters of startup_skew: one buffer per device, allocated on first use (under a lock: launches may come from several host
-// threads), zeroed once; every launch takes a fresh epoch (see startup_skew), so nothing is ever reset
+// threads), zeroed once; every launch takes a fresh epoch (see startup_skew), so nothing is ever reset.  The counter words are per
+// DEVICE, not per stream: two rec2 launches in flight on one device at once (different streams) re-stamp each other's arrival counts,
+// so "second block on this CU" can be decided wrongly for either -- that moves a block's START by half an item, never a result (the
+// plugin and the bench run one stream per device; the heuristic assumes that).
 static unsigned* cu_counters(unsigned* epoch) {
     static std::mutex mu;
     static unsigned* buf[64] = {};
@@ -612,7 +615,10 @@ static unsigned* cu_counters(unsigned* epoch) {
     if (!buf[dev]) {
         unsigned* p = nullptr;
         if (hipMalloc(&p, 16 * 256 * sizeof(unsigned)) != hipSuccess) return nullptr;
-        if (hipMemset(p, 0, 16 * 256 * sizeof(unsigned)) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, 16 * 256 * sizeof(unsigned)) != hipSuccess) {
+            (void)hipFree(p);      // (no counters: this launch runs without the skew; the next one tries again)
+            return nullptr;
+        }
         buf[dev] = p;
     }
     next_epoch[dev] = (next_epoch[dev] + 1u) & 0xFFFFFFu;

@@ -23,7 +23,6 @@ METHOD_MD, METHOD_MOD = 0, 1
 REGION_BG, REGION_FG = 0, 1
 BLEND_PARTIAL, BLEND_TILE_RANGE, BLEND_PACKED = 1, 2, 4
 CONV_UPSAMPLE2X = 1
-CONV_REC_DRIP = 16
 CONV_REC_ONE_BLOCK, CONV_REC_TWO_BLOCKS = 4, 8      # call_rec(family=...): name the record-conv kernel family (tests / probes); 0 = per launch
 CONV_EXACT_F32 = 2
 ATTN_EXACT_F32 = 1
@@ -772,17 +771,16 @@ class PackedConv:
 
     def call_rec(self, x: RecImage, residual: Optional[torch.Tensor] = None, upsample2x: bool = False, want_f32: bool = True,
                  want_rec: bool = False, rec_coef: Optional[torch.Tensor] = None, window: Optional[Tuple[int, int, int, int]] = None,
-                 family: int = 0, stats_groups: int = 0):
-        """y = conv(x_rec) + bias (+ residual) -> (fp32 NCHW or None, RecImage or None).
-        stats_groups = G (fp32 output only; leaves_stats(G, upsample2x, rec=True)): -> (y, None, (var, mean)) with get_var_mean of y from the
-        conv's own epilogue (mdtile_conv2d_rec_stats).  The record output is
+                 family: int = 0):
+        """y = conv(x_rec) + bias (+ residual) -> (fp32 NCHW or None, RecImage or None), always that pair (the statistics-leaving form is
+        call_rec_stats).  The record output is
         split(silu(a y + s)) with rec_coef = gn_coeffs(...) of the NEXT norm, or split(y) when rec_coef is None.
         window = (y0, x0, h, w) in INPUT pixels (upsample2x only; y0, x0: ints, or one int per image): the conv of that window of x,
         outputs [B, cout, 2h, 2w] (mdtile_upconv2d_rec_window: live-window narrowing of a decoder tile)."""
         B, cin, H, W = x.shape
         assert cin == self.cin and (want_f32 or want_rec)
         if window is not None:
-            assert upsample2x and residual is None and not stats_groups, "a window is taken by the upsample conv only"
+            assert upsample2x and residual is None, "a window is taken by the upsample conv only"
             y0, x0, h, w = window
             y0 = [int(y0)] * B if isinstance(y0, int) else [int(v) for v in y0]       # one origin for every image, or one per image
             x0 = [int(x0)] * B if isinstance(x0, int) else [int(v) for v in x0]
@@ -804,13 +802,6 @@ class PackedConv:
         if residual is not None:
             _dev_tensor(residual, "residual", torch.float32)
             assert tuple(residual.shape) == (B, self.cout, H, W)
-        if stats_groups:
-            assert want_f32 and not want_rec and rec_coef is None, "statistics come with the fp32 output only"
-            mean, var, ws = self._stats_buffers(B, H, W, int(stats_groups), x.data.device)
-            _check(lib().mdtile_conv2d_rec_stats(_p(x.data), _p(self.packed), _p(self.bias_rec), _p(residual), _p(y), B, self.cin, self.cout, H, W,
-                                                 (CONV_UPSAMPLE2X if upsample2x else 0) | int(family), int(stats_groups), _p(mean), _p(var), _p(ws),
-                                                 _stream()), "mdtile_conv2d_rec_stats")
-            return y, None, (var, mean)
         if rec_coef is not None:
             _dev_tensor(rec_coef, "rec_coef", torch.float32)
             assert want_rec and tuple(rec_coef.shape) == (B, 2, self.cout)
@@ -819,20 +810,60 @@ class PackedConv:
                "mdtile_conv2d_rec")
         return y, yr
 
+    def call_rec_stats(self, x: RecImage, residual: Optional[torch.Tensor] = None, upsample2x: bool = False, family: int = 0, groups: int = 32):
+        """y = conv(x_rec) + bias (+ residual) as fp32 NCHW AND get_var_mean(y, groups) from the conv's own epilogue
+        (mdtile_conv2d_rec_stats; leaves_stats(groups, upsample2x, rec=True) says where) -> (y, (var, mean)), always that pair."""
+        B, cin, H, W = x.shape
+        assert cin == self.cin
+        if upsample2x:
+            H, W = 2 * H, 2 * W
+        y = torch.empty((B, self.cout, H, W), dtype=torch.float32, device=x.data.device)
+        if residual is not None:
+            _dev_tensor(residual, "residual", torch.float32)
+            assert tuple(residual.shape) == (B, self.cout, H, W)
+        mean, var, ws = self._stats_buffers(B, H, W, int(groups), x.data.device)
+        _check(lib().mdtile_conv2d_rec_stats(_p(x.data), _p(self.packed), _p(self.bias_rec), _p(residual), _p(y), B, self.cin, self.cout, H, W,
+                                             (CONV_UPSAMPLE2X if upsample2x else 0) | int(family), int(groups), _p(mean), _p(var), _p(ws),
+                                             _stream()), "mdtile_conv2d_rec_stats")
+        return y, (var, mean)
+
+    def call_stats(self, x: torch.Tensor, pre_gn: torch.Tensor, residual: Optional[torch.Tensor] = None, groups: int = 32):
+        """y = conv(silu(a * x + s)) (+ residual) on the fp32 hand-over kernel AND get_var_mean(y, groups) from its epilogue
+        (mdtile_conv2d_gn_stats; leaves_stats(groups) says where) -> (y, (var, mean)), always that pair."""
+        _dev_tensor(x, "x", torch.float32)
+        _dev_tensor(pre_gn, "pre_gn", torch.float32)
+        B, cin, H, W = x.shape
+        assert cin == self.cin and tuple(pre_gn.shape) == (B, 2, self.cin)
+        y = torch.empty((B, self.cout, H, W), dtype=torch.float32, device=x.device)
+        if residual is not None:
+            _dev_tensor(residual, "residual", torch.float32)
+            assert residual.shape == y.shape
+        mean, var, ws = self._stats_buffers(B, H, W, int(groups), x.device)
+        _check(lib().mdtile_conv2d_gn_stats(_p(x), _p(pre_gn), _p(self.packed), _p(self.bias), _p(residual), _p(y), B, self.cin, self.cout,
+                                            H, W, self.ksize, 0, int(groups), _p(mean), _p(var), _p(ws), _stream()), "mdtile_conv2d_gn_stats")
+        return y, (var, mean)
+
     def leaves_stats(self, groups: int = 32, upsample2x: bool = False, rec: bool = False) -> bool:
         """True when this conv has a kernel whose epilogue also leaves the GroupNorm statistics of its output (slow mode: the producer of
-        a pooled norm's input): __call__(pre_gn=..., stats_groups=groups), or call_rec(..., stats_groups=groups) with rec=True."""
+        a pooled norm's input): call_stats(x, pre_gn, ...), or call_rec_stats(...) with rec=True."""
         if rec:
             return bool(lib().mdtile_conv2d_rec_stats_supported(self.cout, self.cin, self.ksize, CONV_UPSAMPLE2X if upsample2x else 0, int(groups)))
         return bool(not upsample2x and lib().mdtile_conv2d_gn_stats_supported(self.cout, self.cin, self.ksize, 0, int(groups)))
 
     def _stats_buffers(self, B: int, H: int, W: int, groups: int, device):
+        """(mean, var) rows of one call -- fresh: the caller keeps them (GroupNormParam pools the rows of several tiles) -- and the partials
+        workspace, which only lives inside the call (launches of one stream run in order): ONE buffer per (shape, device), up to ~10 MB."""
         mean = torch.empty(B * groups, dtype=torch.float32, device=device)
-        ws = torch.empty((lib().mdtile_conv_stats_ws_size(B, self.cout, H, W, groups) + 7) // 8, dtype=torch.float64, device=device)
-        return mean, torch.empty_like(mean), ws
+        key = (B, H, W, groups, str(device))
+        cache = self.__dict__.setdefault("_stats_ws", {})
+        if key not in cache:
+            if len(cache) >= 8:
+                cache.clear()
+            cache[key] = torch.empty((lib().mdtile_conv_stats_ws_size(B, self.cout, H, W, groups) + 7) // 8, dtype=torch.float64, device=device)
+        return mean, torch.empty_like(mean), cache[key]
 
     def __call__(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, upsample2x: bool = False,
-                 token_major: bool = False, exact: bool = False, pre_gn: Optional[torch.Tensor] = None, stats_groups: int = 0):
+                 token_major: bool = False, exact: bool = False, pre_gn: Optional[torch.Tensor] = None):
         """exact=True forces the exact-fp32 MFMA kernel; by default 3x3 convs with cin % 16 == 0 run on the split-bf16
         ("bf16x3") matrix-core kernel: fp32 accumulate, ~1e-5 relative to fp32.
         pre_gn = gn_coeffs(...) [B, 2, cin]: y = conv(silu(a * x + s)) -- GroupNorm + SiLU fused into the input staging
@@ -850,16 +881,9 @@ class PackedConv:
         if pre_gn is not None:
             _dev_tensor(pre_gn, "pre_gn", torch.float32)
             assert tuple(pre_gn.shape) == (B, 2, self.cin) and not token_major and not upsample2x
-            if stats_groups:
-                # -> (y, (var, mean)): get_var_mean of y from the conv's own epilogue (leaves_stats() says where)
-                mean, var, ws = self._stats_buffers(B, H, W, int(stats_groups), x.device)
-                _check(lib().mdtile_conv2d_gn_stats(_p(x), _p(pre_gn), _p(self.packed), _p(self.bias), _p(residual), _p(y), B, self.cin, self.cout,
-                                                    H, W, self.ksize, 0, int(stats_groups), _p(mean), _p(var), _p(ws), _stream()), "mdtile_conv2d_gn_stats")
-                return y, (var, mean)
             _check(lib().mdtile_conv2d_gn(_p(x), _p(pre_gn), _p(self.packed), _p(self.bias), _p(residual), _p(y), B, self.cin, self.cout,
                                           H, W, self.ksize, CONV_EXACT_F32 if exact else 0, _stream()), "mdtile_conv2d_gn")
             return y
-        assert not stats_groups, "statistics only from the kernels leaves_stats() names"
         _check(lib().mdtile_conv2d(_p(x), _p(self.packed), _p(self.bias), _p(residual), _p(y), B, self.cin, self.cout, H, W,
                                    self.ksize, (CONV_UPSAMPLE2X if upsample2x else 0) | (CONV_EXACT_F32 if exact else 0),
                                    int(token_major), _stream()), "mdtile_conv2d")

@@ -32,8 +32,16 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
 PROBES_LIB = os.path.join(os.path.dirname(EXT_ROOT), "probes", "_ab", "libmdtile_probes.so")
 
 
+PROBES_CSRC = os.path.join(os.path.dirname(EXT_ROOT), "probes", "csrc")
+
+
 def _sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _probe_sources():
+    """Kernels that exist in the PROBES twin only (measured and rejected forms kept for their A/B scripts): probes/csrc/*.hip."""
+    return sorted(glob.glob(os.path.join(PROBES_CSRC, "*.hip")))
 
 
 def _digest() -> str:
@@ -98,18 +106,18 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 def build_probes(verbose: bool = True) -> str:
-    """The PROBES twin of the library (-DMDTILE_PROBES=1: MDTILE_REC_DBG / _STAMPS / _GRID / _BLOCKS / _PERSIST / _STAGGER_PCT,
+    """The PROBES twin of the library (the shipping sources + probes/csrc/*.hip, -DMDTILE_PROBES=1: MDTILE_REC_DBG / _STAMPS / _GRID / _BLOCKS / _PERSIST / _STAGGER_PCT,
     MDTILE_REC2_*, MDTILE_BLEND_CFG, MDTILE_ATTN_SPLIT, MDTILE_C1X1_STREAM are read per launch) -> probes/_ab/libmdtile_probes.so
     (git-ignored, travels with gpurun).  probes/_probes_lib.py: use(E) points the ctypes binding at it before the first call; never shipped, never the default."""
     hipcc = hipcc_path()
     if hipcc is None:
         raise RuntimeError("hipcc not found")
     os.makedirs(os.path.dirname(PROBES_LIB), exist_ok=True)
-    flags = [f for f in HIPCC_FLAGS if f != "-DMDTILE_PROBES=0"] + ["-DMDTILE_PROBES=1"]
+    flags = [f for f in HIPCC_FLAGS if f != "-DMDTILE_PROBES=0"] + ["-DMDTILE_PROBES=1", "-I" + CSRC]
     objdir = os.path.join(EXT_ROOT, "build", "probes")
     os.makedirs(objdir, exist_ok=True)
     procs, objs = [], []
-    for src in _sources():
+    for src in _sources() + _probe_sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
         procs.append((src, subprocess.Popen([hipcc] + [f for f in flags if f != "-shared"] + ["-c", src, "-o", obj],

@@ -334,7 +334,6 @@ class VAEHook:
         """Advance one tile to its next GroupNorm (exclusive) or to the end.
         want_stats (slow mode, the norm ahead is pooled): the conv that produces the norm's input also leaves its (var, mean) in st.stats
         where a kernel does that in its epilogue (PackedConv.leaves_stats) -- GroupNormParam.add_tile then needs no pass over the tile."""
-        want_stats = want_stats and SLOW_STATS
         while st.pc < len(steps):
             s = steps[st.pc]
             if s.kind == "norm":
@@ -344,28 +343,54 @@ class VAEHook:
             if s.kind == "store_res":
                 st.res.append(st.x if s.conv is None else s.conv(st.x))
             elif s.kind == "conv":
-                stats_fn = getattr(s.conv, "leaves_stats", None) if want_stats and self._feeds_norm(steps, st.pc) else None
-                if s.downsample:
+                route = self._conv_route(s, st.pre is not None, want_stats and self._feeds_norm(steps, st.pc))
+                residual = st.res.pop() if s.fuse_res and route != "down" else None
+                if route == "down":
                     st.x = s.conv.down2(st.x)
-                elif stats_fn is not None and self._pooled_site_takes_rec(s) and stats_fn(32, upsample2x=s.upsample, rec=True):
+                elif route == "rec_stats":
                     xrec = self.engine.rec_from_f32(st.x, st.pre)
-                    st.x, _, st.stats = s.conv.call_rec(xrec, residual=st.res.pop() if s.fuse_res else None, upsample2x=s.upsample, want_f32=True,
-                                                        want_rec=False, stats_groups=32)
-                elif stats_fn is not None and st.pre is not None and not s.upsample and not self._pooled_site_takes_rec(s) and stats_fn(32):
-                    st.x, st.stats = s.conv(st.x, residual=st.res.pop() if s.fuse_res else None, pre_gn=st.pre, stats_groups=32)
-                elif self._pooled_site_takes_rec(s):
+                    st.x, st.stats = s.conv.call_rec_stats(xrec, residual=residual, upsample2x=s.upsample, groups=32)
+                elif route == "handover_stats":
+                    st.x, st.stats = s.conv.call_stats(st.x, st.pre, residual=residual, groups=32)
+                elif route == "rec":
                     # pooled-statistics site on the record kernels: one conversion pass (norm + SiLU fused into it) + the record conv --
                     # the fp32 hand-over kernel's output to fp32 rounding (a fused residual enters the accumulation first here: (res + sum) + bias), cheaper where _pooled_site_takes_rec says so
                     xrec = self.engine.rec_from_f32(st.x, st.pre)
-                    st.x, _ = s.conv.call_rec(xrec, residual=st.res.pop() if s.fuse_res else None, upsample2x=s.upsample, want_f32=True, want_rec=False)
+                    st.x, _ = s.conv.call_rec(xrec, residual=residual, upsample2x=s.upsample, want_f32=True, want_rec=False)
                 else:
-                    st.x = s.conv(st.x, residual=st.res.pop() if s.fuse_res else None, upsample2x=s.upsample, pre_gn=st.pre)
+                    st.x = s.conv(st.x, residual=residual, upsample2x=s.upsample, pre_gn=st.pre)
                 st.pre = None
             elif s.kind == "attn":
                 st.x = s.attn(st.x, st.res.pop())
             elif s.kind == "tanh":
                 st.x = self.engine.tanh(st.x)
             st.pc += 1
+
+    def _conv_route(self, s: Step, has_pre: bool, want_stats: bool = False) -> str:
+        """Which engine call a conv step of the norm-to-norm walk (slow mode, the estimator pass) takes -- THE one place that decides it:
+        _run_until_norm dispatches on it and _apply_norm asks it whether the norm it has just resolved may ride on the conv as pending
+        (a, s) coefficients (`has_pre`), so the two cannot disagree about who applies a norm.
+          "down"            ldm Downsample (stride 2; no norm in front of it)
+          "rec_stats"       conversion pass (takes the pending coefficients) + record conv that leaves get_var_mean of its output
+          "handover_stats"  fp32 hand-over conv applying the pending coefficients while staging + statistics from its epilogue
+          "rec"             conversion pass + record conv (_pooled_site_takes_rec: where that is the cheaper pair)
+          "plain"           the conv's own call: applies pending coefficients only where fuses_pre_gn() says it can"""
+        if s.downsample:
+            return "down"
+        takes_rec = self._pooled_site_takes_rec(s)
+        stats_fn = getattr(s.conv, "leaves_stats", None) if (want_stats and SLOW_STATS) else None
+        if stats_fn is not None and takes_rec and stats_fn(32, upsample2x=s.upsample, rec=True):
+            return "rec_stats"
+        if stats_fn is not None and has_pre and not s.upsample and not takes_rec and stats_fn(32):
+            return "handover_stats"
+        return "rec" if takes_rec else "plain"
+
+    def _norm_rides_on(self, nxt: Optional[Step]) -> bool:
+        """A resolved norm + SiLU in front of `nxt` stays pending as (a, s) coefficients exactly when the route `nxt` will take applies them."""
+        if not (FUSE_PRE_GN and nxt is not None and nxt.kind == "conv" and not nxt.downsample):
+            return False
+        route = self._conv_route(nxt, True)        # (statistics variants of a route apply the coefficients the same way)
+        return (route == "rec" and not nxt.upsample) or (route == "plain" and bool(nxt.conv.fuses_pre_gn(upsample2x=nxt.upsample)))
 
     def _pooled_site_takes_rec(self, s: Step) -> bool:
         """Slow mode / the estimator pass: a norm whose statistics are pooled cannot be applied by the conv that PRODUCES its input, so the
@@ -521,13 +546,13 @@ class VAEHook:
         s = steps[st.pc]
         gamma, beta = s.norm
         nxt = steps[st.pc + 1] if st.pc + 1 < len(steps) else None
-        if (FUSE_PRE_GN and s.silu and nxt is not None and nxt.kind == "conv" and not nxt.downsample
-                and (nxt.conv.fuses_pre_gn(upsample2x=nxt.upsample) or (not nxt.upsample and self._pooled_site_takes_rec(nxt)))):
+        if s.silu and self._norm_rides_on(nxt):
             # norm + SiLU ride on the conv's input staging: only the per-channel (a, s) pair is formed here
             st.pre = E.gn_coeffs(mean, var, gamma, beta, st.x.shape[1], 32, 1e-6)
         else:
             keep = st.res and st.res[-1] is st.x          # identity shortcut: the residual aliases the pre-norm tensor
             st.x = E.gn_apply(st.x, mean, var, gamma, beta, 32, 1e-6, s.silu, out=None if keep else st.x)
+            st.stats = None                               # (var, mean) described the tensor that was just replaced
         st.pc += 1
 
     @torch.no_grad()

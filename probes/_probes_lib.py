@@ -9,9 +9,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "multidiffusion-upscaler-for-automatic1111_amd"))
 
 
+CONV_REC_DRIP = 16      # mdtile_conv2d_rec flag bit of the dripped-epilogue kernel (probes/csrc/vae_conv_recd.hip): the PROBES twin only
+
+
 def use(E):
     from mdtile import build as b
-    if not os.path.exists(b.PROBES_LIB) or os.path.getmtime(b.PROBES_LIB) < max(os.path.getmtime(f) for f in b._sources()):
+    E.CONV_REC_DRIP = CONV_REC_DRIP
+    if not os.path.exists(b.PROBES_LIB) or os.path.getmtime(b.PROBES_LIB) < max(os.path.getmtime(f) for f in b._sources() + b._probe_sources()):
         b.build_probes()
     assert E._lib is None, "probes: the library is already loaded"
     E.LIB_PATH = b.PROBES_LIB

@@ -1,5 +1,5 @@
 """Same-process A/B of the record 3x3 conv kernels (run on the GPU box): ONE 8-wave block per CU with the store epilogue behind
-each item's K loop (csrc/vae_conv_rec.hip, MDTILE_CONV_REC_ONE_BLOCK) against the DRIPPED epilogue (csrc/vae_conv_recd.hip,
+each item's K loop (csrc/vae_conv_rec.hip, MDTILE_CONV_REC_ONE_BLOCK) against the DRIPPED epilogue (probes/csrc/vae_conv_recd.hip,
 MDTILE_CONV_REC_DRIP: 64-cout items, previous item's stores / next item's residual issued in slots between the K-steps).
     python probes/conv_drip_ab.py [--shapes 0,3] [--b 1]
 Prints TFLOP/s-equivalent (2 * B * H * W * cout * cin * 9) per output kind; both families are bit-identical (tests/test_gpu_rec.py)."""
@@ -15,7 +15,7 @@ import mdtile as E
 DBG = None
 if "--kloop" in sys.argv:      # K loops alone (MDTILE_REC_DBG=1 of the PROBES twin: no epilogue / no slots, nothing is written)
     DBG = "1"
-if "--dbg" in sys.argv:        # csrc/vae_conv_recd.hip: 2 no activation arithmetic | 4 no record stores | 8 no fp32 stores | 16 no residual loads
+if "--dbg" in sys.argv:        # probes/csrc/vae_conv_recd.hip: 2 no activation arithmetic | 4 no record stores | 8 no fp32 stores | 16 no residual loads
     DBG = sys.argv[sys.argv.index("--dbg") + 1]
 if DBG is not None:
     sys.path.insert(0, os.path.join(ROOT, "probes"))

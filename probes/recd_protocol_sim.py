@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""CPU model of the request / wait / read schedule of the dripped-epilogue record conv (csrc/vae_conv_recd.hip).
+"""CPU model of the request / wait / read schedule of the dripped-epilogue record conv (probes/csrc/vae_conv_recd.hip).
 
 The kernel requests its operands with hand-issued `global_load_lds_dwordx4` pieces and interleaves them with the slot traffic of the
 previous item's epilogue (global stores) and the next item's residual rows (global loads).  gfx9 counts ALL of these in ONE in-order
@@ -25,7 +25,7 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_spec = importlib.util.spec_from_file_location("rec2_protocol_sim", os.path.join(_HERE, "rec2_protocol_sim.py"))
+_spec = importlib.util.spec_from_file_location("rec2_protocol_sim", os.path.join(os.path.dirname(_HERE), "tools", "rec2_protocol_sim.py"))
 _r2 = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(_r2)
 

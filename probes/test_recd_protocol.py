@@ -1,6 +1,6 @@
-"""CPU check of the request / wait / read schedule of the dripped-epilogue record conv (csrc/vae_conv_recd.hip): operand DMA, slot
+"""CPU check of the request / wait / read schedule of the dripped-epilogue record conv (probes/csrc/vae_conv_recd.hip; PROBES twin only since round 6): operand DMA, slot
 stores and residual loads share ONE in-order vmcnt; the waits in front of the phase barriers count lower bounds of what the slots
-issued.  tools/recd_protocol_sim.py re-states the kernel's loops (slot trip + plain trips, three pieces per phase, the two wave
+issued.  probes/recd_protocol_sim.py re-states the kernel's loops (slot trip + plain trips, three pieces per phase, the two wave
 groups passing a phase's barrier half a step apart) on the adversarial memory model of tools/rec2_protocol_sim.py."""
 import importlib.util
 import inspect
@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _sim():
-    spec = importlib.util.spec_from_file_location("recd_protocol_sim", os.path.join(ROOT, "tools", "recd_protocol_sim.py"))
+    spec = importlib.util.spec_from_file_location("recd_protocol_sim", os.path.join(ROOT, "probes", "recd_protocol_sim.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
@@ -50,7 +50,7 @@ def test_the_model_rejects_looser_waits():
 def test_source_constants_match_the_kernel():
     """the lower bounds and the slot map of the model are the kernel's"""
     sim = _sim()
-    hip = open(os.path.join(ROOT, "multidiffusion-upscaler-for-automatic1111_amd", "csrc", "vae_conv_recd.hip")).read()
+    hip = open(os.path.join(ROOT, "probes", "csrc", "vae_conv_recd.hip")).read()
     assert "if (big) { MDT_VMCNT(15); counted = true; }" in hip and "MDT_VMCNT(2); counted = true;" in hip and "MDT_VMCNT(5);" in hip
     assert "constexpr int D_TK = 4;" in hip and sim.D_TK == 4
     assert "return p % 3 == 0 ? -1 : 2 * (p / 3) + p % 3 - 1;" in hip

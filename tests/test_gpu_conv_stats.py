@@ -61,7 +61,7 @@ def test_handover_conv_leaves_the_statistics_of_its_output(plugin, cuda, B, cin,
     coef = _coef(B, cin, 5).to(cuda)
     r = torch.randn(B, cout, H, W).to(cuda) if res else None
     y0 = pc(x, residual=r, pre_gn=coef)
-    y1, (var, mean) = pc(x, residual=r, pre_gn=coef, stats_groups=32)
+    y1, (var, mean) = pc.call_stats(x, coef, residual=r, groups=32)
     assert torch.equal(y0, y1), "the statistics kernel must not change y"
     _check(var, mean, y1, f"hand-over {cin}->{cout} {H}x{W}")
     v2, m2 = E.gn_stats(y1, 32)
@@ -95,8 +95,8 @@ def test_record_conv_leaves_the_statistics_of_its_output(plugin, cuda, B, cin, c
     r = torch.randn(B, cout, H, W).to(cuda) if res else None
     fam = E.CONV_REC_ONE_BLOCK if family == 1 else 0
     y0, _ = pc.call_rec(xrec, residual=r, upsample2x=up, want_f32=True, want_rec=False, family=fam)
-    y1, none, (var, mean) = pc.call_rec(xrec, residual=r, upsample2x=up, want_f32=True, want_rec=False, family=fam, stats_groups=32)
-    assert none is None and torch.equal(y0, y1), "the statistics kernel must not change y"
+    y1, (var, mean) = pc.call_rec_stats(xrec, residual=r, upsample2x=up, family=fam, groups=32)
+    assert torch.equal(y0, y1), "the statistics kernel must not change y"
     _check(var, mean, y1, f"record {'upconv' if up else 'conv'} {cin}->{cout} {H}x{W} family {family}")
 
 

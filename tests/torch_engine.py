@@ -32,7 +32,7 @@ class TorchConv:
         small test decoders: couts in whole groups of >= 1."""
         return self.ksize == 3 and not self.down and self.cout % groups == 0 and (rec or not upsample2x)
 
-    def __call__(self, x, residual=None, upsample2x=False, token_major=False, exact=False, pre_gn=None, stats_groups=0):
+    def __call__(self, x, residual=None, upsample2x=False, token_major=False, exact=False, pre_gn=None):
         if pre_gn is not None:
             x = F.silu(x * pre_gn[:, 0, :, None, None] + pre_gn[:, 1, :, None, None])
         if upsample2x:
@@ -43,11 +43,14 @@ class TorchConv:
         if token_major:
             B, C, H, W = y.shape
             y = y.permute(0, 2, 3, 1).reshape(B, H * W, C).contiguous()
-        if stats_groups:
-            assert pre_gn is not None and not token_major
-            TorchConv.stats_left += 1
-            return y, vo.get_var_mean(y, stats_groups)
         return y
+
+    def call_stats(self, x, pre_gn, residual=None, groups=32):
+        """PackedConv.call_stats: always (y, (var, mean))."""
+        assert pre_gn is not None
+        y = self(x, residual=residual, pre_gn=pre_gn)
+        TorchConv.stats_left += 1
+        return y, vo.get_var_mean(y, groups)
 
     def down2(self, x):
         return self.conv(F.pad(x, (0, 1, 0, 1)))
@@ -170,7 +173,13 @@ class TorchConvRec(TorchConv):
     def takes_rec(self, upsample2x=False):
         return self.ksize == 3 and not self.down and self.cin % 32 == 0 and self.cout % 32 == 0
 
-    def call_rec(self, xrec, residual=None, upsample2x=False, want_f32=True, want_rec=False, rec_coef=None, window=None, stats_groups=0):
+    def call_rec_stats(self, xrec, residual=None, upsample2x=False, family=0, groups=32):
+        """PackedConv.call_rec_stats: always (y, (var, mean))."""
+        y, _ = self.call_rec(xrec, residual=residual, upsample2x=upsample2x, want_f32=True, want_rec=False)
+        TorchConv.stats_left += 1
+        return y, vo.get_var_mean(y, groups)
+
+    def call_rec(self, xrec, residual=None, upsample2x=False, want_f32=True, want_rec=False, rec_coef=None, window=None, family=0):
         x = xrec.t
         if window is not None:
             # mdtile_upconv2d_rec_window: the conv of a window of the input whose edges inside the image see the true neighbours ==
@@ -196,20 +205,16 @@ class TorchConvRec(TorchConv):
         yr = None
         if want_rec:
             yr = TorchRec(F.silu(y * rec_coef[:, 0, :, None, None] + rec_coef[:, 1, :, None, None]) if rec_coef is not None else y)
-        if stats_groups:
-            assert want_f32 and not want_rec and window is None
-            TorchConv.stats_left += 1
-            return y, None, vo.get_var_mean(y, stats_groups)
         return (y if want_f32 else None), yr
 
 
 class TorchConvCounting(TorchConv):
     """TorchConv (no record form) that books its output elements in the same counter as TorchConvRec."""
 
-    def __call__(self, x, residual=None, upsample2x=False, token_major=False, exact=False, pre_gn=None, stats_groups=0):
-        out = super().__call__(x, residual, upsample2x, token_major, exact, pre_gn, stats_groups)
+    def __call__(self, x, residual=None, upsample2x=False, token_major=False, exact=False, pre_gn=None):
+        out = super().__call__(x, residual, upsample2x, token_major, exact, pre_gn)
         if self.ksize == 3:
-            TorchConvRec.px_computed += (out[0] if stats_groups else out).numel()
+            TorchConvRec.px_computed += out.numel()
         return out
 
 

@@ -11,7 +11,7 @@ device assembly and checks the emitted instruction stream instead:
       the ones the source asks for: {0, 5} in k_conv3x3_rec (the 5 input pieces of the next K-step may stay in flight at dy = 1),
       {0} in k_upconv_rec and k_attn_bf16x3 (lgkmcnt-only waits -- LDS hand-overs that consume no DMA -- are reported separately),
       {0, 2, 3, 4} in k_conv3x3_rec2 and {0, 6, 7, 8, 9} in k_upconv_rec2 (one counted wait per step position, csrc/vae_conv_rec2.hip),
-      {0, 2, 5, 15} in k_conv3x3_recd (csrc/vae_conv_recd.hip: the dripped epilogue's slot traffic may stay in flight behind the chunk)
+      {0, 2, 5, 15} in k_conv3x3_recd (probes/csrc/vae_conv_recd.hip, checked with --probes only: the dripped epilogue's slot traffic may stay in flight behind the chunk)
     * MFMA counts per unrolled trip match the source (conv: 36 half-steps x 12; upconv: 24 combo-steps x 12; attention: 24 / slab)
 usage: python tools/asm_guard.py   (exit code 0 = ok; prints one line per kernel)      -- also run by tests/test_host_abi.py
 """
@@ -35,13 +35,13 @@ from mdtile.build import HIPCC_FLAGS, hipcc_path  # noqa: E402
 FLAGS = [f for f in HIPCC_FLAGS if f not in ("-shared",)] + ["-S", "--cuda-device-only"]
 
 
-def device_asm(src: str) -> list:
+def device_asm(src: str, extra=()) -> list:
     hipcc = hipcc_path()
     if hipcc is None:
         raise RuntimeError("hipcc not found")
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "k.s")
-        r = subprocess.run([hipcc] + FLAGS + [src, "-o", out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        r = subprocess.run([hipcc] + FLAGS + list(extra) + [src, "-o", out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc -S failed on {src}:\n{r.stdout}")
         return open(out).read().splitlines()
@@ -117,7 +117,9 @@ def main() -> int:
     errs = []
     rec = kernels(device_asm(os.path.join(CSRC, "vae_conv_rec.hip")))
     rec2 = kernels(device_asm(os.path.join(CSRC, "vae_conv_rec2.hip")))
-    recd = kernels(device_asm(os.path.join(CSRC, "vae_conv_recd.hip")))
+    # --probes: also the kernels that exist in the PROBES twin only (probes/csrc/: the dripped-epilogue conv, a measured and rejected form)
+    probes_csrc = os.path.join(ROOT, "probes", "csrc")
+    recd = kernels(device_asm(os.path.join(probes_csrc, "vae_conv_recd.hip"), ["-I" + CSRC])) if "--probes" in sys.argv else None
     att = kernels(device_asm(os.path.join(CSRC, "vae_attn_bf16x3.hip")))
     c11 = kernels(device_asm(os.path.join(CSRC, "vae_conv1x1_bf16x3.hip")))
     plan = [
@@ -132,12 +134,12 @@ def main() -> int:
         # two blocks per CU: one counted wait per step position (tools/rec2_protocol_sim.py derives and checks the values)
         (rec2, "k_conv3x3_rec2ILi2ELi2ELi4", dict(dma_min=8, barrier_vmcnt=[0, 2, 3, 4], mfma_multiple=12)),
         (rec2, "k_upconv_rec2E", dict(dma_min=8, barrier_vmcnt=[0, 6, 7, 8, 9], mfma_multiple=12)),
-        # dripped epilogue: vmcnt(5) at dy = 1, and behind a slot phase a lower bound of the slot's own memory instructions (15 / 2)
-        (recd, "k_conv3x3_recdE", dict(dma_min=8, barrier_vmcnt=[0, 2, 5, 15], mfma_multiple=12)),
         (att, "k_attn_bf16x3ILi512", dict(dma_min=8, barrier_vmcnt=[0], mfma_multiple=6)),
         (att, "k_attn_bf16x3ILi256", dict(dma_min=8, barrier_vmcnt=[0], mfma_multiple=6)),
         (att, "k_attn_bf16x3ILi128", dict(dma_min=8, barrier_vmcnt=[0], mfma_multiple=6)),
     ]
+    if recd is not None:      # dripped epilogue: vmcnt(5) at dy = 1, and behind a slot phase a lower bound of the slot's own memory instructions (15 / 2)
+        plan.append((recd, "k_conv3x3_recdE", dict(dma_min=8, barrier_vmcnt=[0, 2, 5, 15], mfma_multiple=12)))
     for table, sub, expect in plan:
         hit = [n for n in table if sub in n]
         if not hit:

@@ -23,7 +23,7 @@ sys.path.insert(0, os.path.join(ROOT, PKG))
 import asm_guard as ag                      # noqa: E402
 from mdtile.build import HIPCC_FLAGS, hipcc_path   # noqa: E402
 
-DEFAULT = ["vae_conv_rec.hip", "vae_conv_rec2.hip", "vae_conv_recd.hip", "vae_conv_bf16x3.hip", "vae_conv1x1_bf16x3.hip", "vae_attn_bf16x3.hip", "blend.hip"]
+DEFAULT = ["vae_conv_rec.hip", "vae_conv_rec2.hip", "vae_conv_bf16x3.hip", "vae_conv1x1_bf16x3.hip", "vae_attn_bf16x3.hip", "blend.hip"]
 
 
 def asm(src: str) -> dict:
