@@ -4,6 +4,8 @@ bench.py -- latent-px/s of the tile-blend + tiled-VAE-decode hot path on an 8K i
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --gpus N ...                     (no launcher environment: bench.py starts its N ranks itself, same line, rc 0)
+    python bench.py --gpus N --single-process ...    (ONE process driving N devices: mdtile_shard_init + VAEHook.devices, the form a webui uses)
 
 One "step" = the whole hot path for ONE 8192x8192 image (latent 1024x1024, SDXL config of BASELINE.json):
     `--evals` (20) model evaluations of  [ tile gather (K2) -> overlap blend (K3-K7) ]   with 128x128 tiles, overlap 8,
@@ -76,6 +78,11 @@ def parse():
     ap.add_argument("--encode-side", type=int, default=8192)
     ap.add_argument("--encode-tile", type=int, default=3072)
     ap.add_argument("--cpu-vae-latent", type=int, default=88, help="width of the 64-row latent of the CPU VAE sample")
+    ap.add_argument("--no-companions", action="store_true", help="skip the `companions` object (the other configurations of SURVEY section 8d: slow mode, "
+                    "encode, cfg3 MoD + decode at tile 256 / 64, cfg2 / cfg4@ov64 / cfg5 blends; untimed for the headline, ~60 s)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="N > 1 inside ONE process: the blend through mdtile.Shard(dev_ids) + ShardedBlend (row bands, halo exchange behind the C ABI), the "
+                         "decode through VAEHook.devices (tiles dealt to the devices, one stream each) -- what an A1111 process can use (SURVEY 8e)")
     ap.add_argument("--debug-single-device", action="store_true",
                     help="functional check of the N > 1 flow on ONE GPU: every rank uses cuda:0 and gloo (host-staged) instead "
                          "of RCCL; the numbers it prints are meaningless")
@@ -115,6 +122,283 @@ class Profile:
             a[2] += s.elapsed_time(e) * 1e-3
         return agg
 
+def _free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with no launcher environment (no WORLD_SIZE): start the N ranks here -- the same
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>` the driver's documented
+    command uses, on this file with the same arguments -- and hand its exit code on.  Rank 0 of the children prints the one JSON line
+    (this process prints nothing on stdout).  On a box with fewer than N GPUs the ranks share cuda:0 over gloo (`--debug-single-device`:
+    the complete N-rank flow as a functional run; the line says so in `transport` / `devices_visible`)."""
+    import subprocess
+    visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if visible < 1:
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback path exists in the product)")
+    argv = list(sys.argv[1:])
+    if visible < args.gpus and "--debug-single-device" not in argv:
+        argv.append("--debug-single-device")
+        print(f"[bench] {visible} GPU(s) visible, {args.gpus} ranks asked for: every rank uses cuda:0 and gloo (functional run of the N-rank flow; "
+              "its numbers say nothing about scaling)", file=sys.stderr)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MDTILE_BENCH_LAUNCHER="bench.py (spawned torch.distributed.run itself)")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL / device-memory sharing across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env).returncode
+
+
+class Instrument:
+    """Context manager: a HIP-event pair around every conv / attention launch the engine's Python entry points make, booked under the
+    kernel symbol (family) the C ABI dispatches that call to.  The events sit on torch's current stream = the stream of the launch."""
+
+    def __init__(self, E, prof: Profile):
+        self.E, self.prof = E, prof
+
+    def __enter__(self):
+        E, prof = self.E, self.prof
+        PC = E.PackedConv
+        bfx = E.get_precision() == E.PRECISION_BF16X3
+        self._saved = (PC.__call__, PC.call_rec, PC.down2, E.vae_attn, PC.call_stats, PC.call_rec_stats)
+        o_call, o_rec, o_down, o_attn, o_cs, o_crs = self._saved
+
+        def handover(self_, x, upsample2x, token_major, exact):
+            B, cin, H, W = x.shape
+            if upsample2x:
+                H, W = 2 * H, 2 * W
+            flops = 2.0 * B * H * W * self_.cout * cin * self_.ksize * self_.ksize
+            bf = bfx and not exact and not token_major and cin % 16 == 0
+            if self_.ksize == 1:
+                tag = "k_conv1x1_stream<*> / k_conv1x1_bf16x3<*>" if (bf and cin % 32 == 0) else "k_conv<1,*> (exact fp32 MFMA)"
+            elif upsample2x and bf:
+                flops *= 4.0 / 9.0      # sub-pixel form of nearest-2x + 3x3 conv: four 2x2 convs -> 4/9 of the MACs are EXECUTED
+                tag = "k_upconv_bf16x3<*> (fp32 hand-over)"
+            else:
+                tag = "k_conv3x3_bf16x3<*> (fp32 hand-over)" if bf else "k_conv3x3_fewcin<*> (conv_in, fp32 FMA)" if cin in (3, 4) and not token_major \
+                    else "k_conv<3,*> (exact fp32 MFMA)"
+            return tag, flops
+
+        def rec(self_, x, upsample2x, window):
+            # record kernels: the tag IS the kernel symbol mdtile_conv2d_rec launches (csrc/vae_conv_rec.hip, dispatch at the end)
+            B, cin, H, W = x.shape
+            if window is not None:
+                H, W = window[2], window[3]      # live-window narrowing: the flops EXECUTED are those of the window
+            if upsample2x:
+                H, W = 2 * H, 2 * W
+            flops = 2.0 * B * H * W * self_.cout * cin * 9
+            if upsample2x:
+                return "k_upconv_rec", flops * 4.0 / 9.0
+            return ("k_conv3x3_rec<2, 2, 4>" if self_.cout % 128 == 0 else "k_conv3x3_rec<1, 1, 2>"), flops
+
+        def t_call(self_, x, residual=None, upsample2x=False, token_major=False, exact=False, pre_gn=None):
+            tag, flops = handover(self_, x, upsample2x, token_major, exact)
+            return prof.wrap(tag, flops, lambda: o_call(self_, x, residual, upsample2x, token_major, exact, pre_gn))
+
+        def t_cs(self_, x, pre_gn, residual=None, groups=32):
+            tag, flops = handover(self_, x, False, False, False)
+            return prof.wrap(tag, flops, lambda: o_cs(self_, x, pre_gn, residual, groups))
+
+        def t_rec(self_, x, residual=None, upsample2x=False, want_f32=True, want_rec=False, rec_coef=None, window=None, family=0):
+            tag, flops = rec(self_, x, upsample2x, window)
+            return prof.wrap(tag, flops, lambda: o_rec(self_, x, residual, upsample2x, want_f32, want_rec, rec_coef, window, family))
+
+        def t_crs(self_, x, residual=None, upsample2x=False, family=0, groups=32):
+            tag, flops = rec(self_, x, upsample2x, None)
+            return prof.wrap(tag, flops, lambda: o_crs(self_, x, residual, upsample2x, family, groups))
+
+        def t_down(self_, x):
+            B, cin, H, W = x.shape
+            ho, wo = (H - 2) // 2 + 1, (W - 2) // 2 + 1
+            return prof.wrap("k_conv3x3_bf16x3<*, false, 2> (Downsample)" if bfx else "k_conv<3,*,2> (exact fp32 MFMA)", 2.0 * B * ho * wo * self_.cout * cin * 9,
+                             lambda: o_down(self_, x))
+
+        def t_attn(q, k, v, scale, exact=False, v_channel_major=False):
+            B, Cc, T = q.shape
+            return prof.wrap("k_attn_bf16x3<512>" if bfx and not exact and Cc == 512 else "k_attn_bf16x3<*>" if bfx and not exact else "k_attn<*> (exact fp32 MFMA)",
+                             4.0 * B * T * T * Cc, lambda: o_attn(q, k, v, scale, exact, v_channel_major))
+
+        PC.__call__, PC.call_rec, PC.down2, E.vae_attn, PC.call_stats, PC.call_rec_stats = t_call, t_rec, t_down, t_attn, t_cs, t_crs
+        return self
+
+    def __exit__(self, *exc):
+        PC = self.E.PackedConv
+        PC.__call__, PC.call_rec, PC.down2, self.E.vae_attn, PC.call_stats, PC.call_rec_stats = self._saved
+        return False
+
+
+def _quiet(fn):
+    """Run fn() with the plugin's progress chatter kept off stdout (the JSON line must stay the only line there)."""
+    import builtins
+    keep = builtins.print
+    builtins.print = lambda *a, **k: None
+    try:
+        return fn()
+    finally:
+        builtins.print = keep
+
+
+def err_metrics(out: torch.Tensor, ref: torch.Tensor):
+    """(max |d| / max |ref|, rms(d) / max |ref|, ||d||_2 / ||ref||_2): the range-normalised figures every parity leg has printed since
+    round 2, and the relative L2 error (the stricter reading of "1e-3 rel-err")."""
+    d = (out.float() - ref.float())
+    den = ref.float().abs().max().item()
+    l2 = (d.double().pow(2).sum().sqrt() / ref.double().pow(2).sum().sqrt()).item()
+    return float(d.abs().max().item() / den), float((d.pow(2).mean().sqrt() / den).item()), float(l2)
+
+
+def measure_vae(E, hook, x, runs: int = 1):
+    """One tiled VAE pass three ways: warm (untimed), `runs` timed passes on the wall clock, one instrumented pass whose per-launch HIP-event
+    times are summed -- kernel_sum / wall says how much of the pass is GPU kernels of the conv / attention families (the rest: host gaps,
+    the small elementwise / statistics / crop kernels)."""
+    _quiet(lambda: hook(x))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(runs):
+        y = _quiet(lambda: hook(x))
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / runs
+    prof = Profile()
+    with Instrument(E, prof):
+        _quiet(lambda: hook(x))
+    agg = {k: v for k, v in prof.summary().items() if k.startswith("k_")}
+    ksum = sum(v[2] for v in agg.values()) * 1e3
+    top = sorted(agg.items(), key=lambda kv: -kv[1][2])[:3]
+    del y
+    return {"ms": round(ms, 2), "kernel_sum_ms": round(ksum, 2), "kernel_sum_over_wall": round(ksum / ms, 4),
+            "top_kernels_ms": {k: round(v[2] * 1e3, 2) for k, v in top}}
+
+
+def blend_setup(E, dev, W, H, tile, overlap, tile_bs, method_name, region_fracs=(), N=2, C=4, seed=1):
+    """Engine-level state of one blend configuration, as the delegates build it (tile_methods/*.py: init_grid_bbox, init_custom_bbox, init_done):
+    plan, weight map (+ 1 per background region for MD, Gaussian layers + reciprocal for MoD), pre-generated tile / region outputs ~N(0,1),
+    the marshalled gather and blend calls and the blend's algorithmic bytes."""
+    import math
+    method = E.METHOD_MD if method_name == "md" else E.METHOD_MOD
+    plan = E.Plan(W, H, tile, tile, overlap, tile_bs)
+    weights = torch.zeros(1, 1, H, W, device=dev)
+    tile_w = E.gaussian_weights(plan.tile_w, plan.tile_h, dev) if method == E.METHOD_MOD else None
+    E.weight_map_add_grid(plan, tile_w, weights)
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    specs, region_bytes = [], 0
+    rects = []
+    for (fx, fy, fw, fh, mode, fr) in region_fracs:
+        x, y = max(0, int(fx * W)), max(0, int(fy * H))
+        w, h = min(W - x, math.ceil(fw * W)), min(H - y, math.ceil(fh * H))
+        rects.append((x, y, w, h, mode, fr))
+    rw = []
+    for (x, y, w, h, mode, fr) in rects:
+        if mode == "bg":
+            cw = E.gaussian_weights(w, h, dev) if method == E.METHOD_MOD else None
+            E.weight_map_add_rect(weights, x, y, w, h, cw, 1.0)
+            rw.append(cw)
+        else:
+            rw.append(E.feather_mask(w, h, fr, dev))
+    rescale = None
+    if method == E.METHOD_MOD:
+        rescale = E.reciprocal(weights)
+        for k, (x, y, w, h, mode, fr) in enumerate(rects):
+            if mode == "bg":
+                E.rect_mul_canvas(rw[k], rescale, x, y, w, h)
+    for k, (x, y, w, h, mode, fr) in enumerate(rects):
+        out = torch.randn(N, C, h, w, generator=g).to(dev)
+        specs.append(E.RegionSpec(x, y, w, h, E.REGION_BG if mode == "bg" else E.REGION_FG, out, rw[k]))
+        region_bytes += 4 * N * C * h * w + (4 * h * w if rw[k] is not None else 0)
+    x_in = torch.randn(N, C, H, W, generator=g).to(dev)
+    tile_out = torch.randn(plan.num_tiles * N, C, plan.tile_h, plan.tile_w, generator=g).to(dev)
+    x_tiles = torch.empty_like(tile_out)
+    out = torch.empty(N, C, H, W, device=dev)
+    kw = dict(weights=weights) if method == E.METHOD_MD else dict(tile_w=tile_w, rescale=rescale)
+    gather = E.GatherRangeCall(plan, x_in, x_tiles, 0, plan.num_tiles)
+    blend = E.BlendCall(plan, method, [tile_out], N, C, out=out, packed=True, regions=specs, **kw)
+    nbytes = 4 * (plan.num_tiles * N * C * plan.tile_h * plan.tile_w + N * C * H * W) + 4 * H * W * (1 if method == E.METHOD_MD else 2) + region_bytes
+    return plan, gather, blend, nbytes
+
+
+def time_launches(calls, n: int = 20, rounds: int = 5):
+    """Median over `rounds` of the time of `n` back-to-back launches (rotating through `calls`) between ONE pair of HIP events on the launch
+    stream, per launch in seconds (an event pair per launch would time the host's launch latency while the GPU idles)."""
+    for c in calls[:3]:
+        c()
+    ts = []
+    for _ in range(rounds):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for i in range(n):
+            calls[i % len(calls)]()
+        e.record()
+        torch.cuda.synchronize()
+        ts.append(s.elapsed_time(e) * 1e-3 / n)
+    return sorted(ts)[len(ts) // 2]
+
+
+def blend_companion(E, dev, W, H, tile, overlap, method_name, region_fracs=()):
+    """One blend configuration of SURVEY section 8(d) as a companion figure: the blend kernel per launch (HIP events, 20 back to back) and the
+    evaluation (tile gather + blend, as the sampler loop issues them) on the wall clock."""
+    plan, gather, blend, nbytes = blend_setup(E, dev, W, H, tile, overlap, 4, method_name, region_fracs)
+    t_k = time_launches([blend])
+    for _ in range(3):
+        gather(); blend()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        gather(); blend()
+    torch.cuda.synchronize()
+    t_eval = (time.perf_counter() - t0) / 20
+    return {"blend_us": round(t_k * 1e6, 2), "eval_wall_us": round(t_eval * 1e6, 2), "blend_over_eval": round(t_k / t_eval, 4),
+            "tiles": plan.num_tiles, "tile": [plan.tile_w, plan.tile_h], "overlap": plan.overlap, "latent": [W, H], "regions": len(region_fracs),
+            "method": method_name, "bytes_per_launch": int(nbytes), "GBps": round(nbytes / t_k / 1e9, 1),
+            "frac_of_hbm_peak": round(nbytes / t_k / 1e9 / HBM_PEAK_GBS, 4)}
+
+
+def run_companions(args, E, pl, ld, dev, dec, z, t_blend_eval):
+    """The other configurations SURVEY section 8(d) names, on the driver's default line: untimed for the headline,
+    each with its own clock and its kernel-sum / wall ratio.  All on this GPU, default precision, same decoder weights as the headline."""
+    out = {}
+    tv = pl.tilevae
+    t_all = time.perf_counter()
+    # --- slow-mode GroupNorm (pooled per norm across tiles, upstream tilevae.py:289-361) on the SAME 8K latent at the bench's decoder tile
+    hook = tv.VAEHook(dec, args.vae_tile, is_decoder=True, fast_decoder=False, fast_encoder=False, color_fix=False)
+    m = measure_vae(E, hook, z)
+    out["slow_vae_ms"] = {"step_ms": round(args.evals * t_blend_eval * 1e3 + m["ms"], 2), "decode": m,
+                          "what": f"the headline step with slow-mode GroupNorm: {args.evals} x blend evaluation + tiled decode of the {args.latent}x{args.latent} latent at decoder tile {args.vae_tile}"}
+    del hook
+    torch.cuda.empty_cache()
+    # --- cfg3: 4096^2 Mixture-of-Diffusers (Gaussian weights, 96 / 48) + tiled decode at tile 256 and at tile 64 (fast mode)
+    b3 = blend_companion(E, dev, 512, 512, 96, 48, "mod")
+    z3 = torch.randn(1, 4, 512, 512, generator=torch.Generator(device="cpu").manual_seed(3)).to(dev)
+    for name, ts in (("cfg3_mod_tile256_ms", 256), ("cfg3_tile64_ms", 64)):
+        hook = tv.VAEHook(dec, ts, is_decoder=True, fast_decoder=True, fast_encoder=False, color_fix=False)
+        m = measure_vae(E, hook, z3, runs=2)
+        out[name] = {"step_ms": round(args.evals * b3["eval_wall_us"] * 1e-3 + m["ms"], 2), "decode": m, "blend": b3 if ts == 256 else None,
+                     "what": f"BASELINE cfg3: 4096x4096 (latent 512x512), {args.evals} x Mixture-of-Diffusers blend (100 tiles 96x96, overlap 48) + tiled VAE decode at tile {ts}, fast mode"}
+        del hook
+    del z3
+    torch.cuda.empty_cache()
+    # --- blend-only configurations: cfg2 (2048^2 MD 96 / 48), cfg4 at overlap 64 (225 tiles), cfg5 (4096 x 1024 panorama + 3 regions)
+    out["cfg2_blend_us"] = blend_companion(E, dev, 256, 256, 96, 48, "md")
+    out["cfg4_ov64_blend_us"] = blend_companion(E, dev, 1024, 1024, 128, 64, "md")
+    regs = [(0.0, 0.0, 0.4, 1.0, "bg", 0.2), (0.3, 0.0, 0.4, 1.0, "bg", 0.2), (0.6, 0.1, 0.4, 0.8, "fg", 0.2)]
+    out["cfg5_regions_blend_us"] = blend_companion(E, dev, 512, 128, 96, 48, "md", regs)
+    torch.cuda.empty_cache()
+    # --- the ENCODE direction (SURVEY 8 f1): 8192^2 image at encoder tile 3072 (upstream's recommendation for large VRAM), fast mode
+    enc = ld.make_encoder(0).to(dev)
+    enc.original_forward = enc.forward
+    hook = tv.VAEHook(enc, args.encode_tile, is_decoder=False, fast_decoder=False, fast_encoder=True, color_fix=False)
+    xi = torch.randn(1, 3, args.encode_side, args.encode_side, generator=torch.Generator().manual_seed(1)).to(dev)
+    m = measure_vae(E, hook, xi)
+    out["encode_ms"] = {"step_ms": m["ms"], "encode": m, "latent_px_per_s": round((args.encode_side // 8) ** 2 / (m["ms"] * 1e-3), 1),
+                        "what": f"tiled VAE ENCODE of a {args.encode_side}x{args.encode_side} image at encoder tile {args.encode_tile}, fast mode (`bench.py --encode` prints its own line with parity)"}
+    del hook, enc, xi
+    torch.cuda.empty_cache()
+    out["seconds"] = round(time.perf_counter() - t_all, 1)
+    out["what"] = ("companion figures, untimed for the headline: one warm + timed pass(es) + one HIP-event-instrumented pass each; `kernel_sum_over_wall` = the conv / "
+                   "attention launches' event time over the pass's wall time")
+    return out
+
 
 def run_encode(args, E, pl, ld, dev):
     """`--encode`: the tiled VAE ENCODE (upstream scripts/tilevae.py:155-171 Downsample tasks, :492-496 encoder estimator, :507-656 the tile
@@ -147,39 +431,8 @@ def run_encode(args, E, pl, ld, dev):
     lat = (side // 8) * (side // 8)
     # per-kernel roofline of one more encode (HIP events around every conv / attention launch, same stream)
     prof = Profile()
-    orig_call, orig_down, orig_attn, orig_rec = E.PackedConv.__call__, E.PackedConv.down2, E.vae_attn, E.PackedConv.call_rec
-    bfx = E.get_precision() == E.PRECISION_BF16X3
-
-    def timed_rec(self, xx, residual=None, upsample2x=False, want_f32=True, want_rec=False, rec_coef=None, window=None, family=0, **kw):
-        B, cin, H, W = xx.shape
-        tag = "k_conv3x3_rec<2, 2, 4> + k_conv3x3_rec2<2, 2, 4>" if self.cout % 128 == 0 else "k_conv3x3_rec<1, 1, 2>"
-        return prof.wrap(tag, 2.0 * B * H * W * self.cout * cin * 9, lambda: orig_rec(self, xx, residual, upsample2x, want_f32, want_rec, rec_coef, window, family, **kw))
-
-    def timed_call(self, xx, residual=None, upsample2x=False, token_major=False, exact=False, pre_gn=None, **kw):
-        B, cin, H, W = xx.shape
-        flops = 2.0 * B * H * W * self.cout * cin * self.ksize * self.ksize
-        bf = bfx and not exact and not token_major and cin % 16 == 0
-        tag = ("k_conv1x1_stream<*> / k_conv1x1_bf16x3<*>" if (bf and cin % 32 == 0) else "k_conv<1,*> (exact fp32 MFMA)") if self.ksize == 1 else \
-              ("k_conv3x3_bf16x3<*> (fp32 hand-over)" if bf else "k_conv3x3_fewcin<*> (conv_in, fp32 FMA)" if cin in (3, 4) and not upsample2x and not token_major
-               else "k_conv<3,*> (exact fp32 MFMA)")
-        return prof.wrap(tag, flops, lambda: orig_call(self, xx, residual, upsample2x, token_major, exact, pre_gn, **kw))
-
-    def timed_down(self, xx):
-        B, cin, H, W = xx.shape
-        ho, wo = (H - 2) // 2 + 1, (W - 2) // 2 + 1
-        return prof.wrap("k_conv3x3_bf16x3<*, false, 2> (Downsample)" if bfx else "k_conv<3,*,2> (exact fp32 MFMA)", 2.0 * B * ho * wo * self.cout * cin * 9,
-                         lambda: orig_down(self, xx))
-
-    def timed_attn(q, k, v, scale, exact=False, v_channel_major=False):
-        B, Cc, T = q.shape
-        return prof.wrap("k_attn_bf16x3<512>" if bfx and not exact else "k_attn<*> (exact fp32 MFMA)", 4.0 * B * T * T * Cc,
-                         lambda: orig_attn(q, k, v, scale, exact, v_channel_major))
-
-    E.PackedConv.__call__, E.PackedConv.down2, E.vae_attn, E.PackedConv.call_rec = timed_call, timed_down, timed_attn, timed_rec
-    try:
+    with Instrument(E, prof):
         quiet(lambda: hook(x))
-    finally:
-        E.PackedConv.__call__, E.PackedConv.down2, E.vae_attn, E.PackedConv.call_rec = orig_call, orig_down, orig_attn, orig_rec
     agg = prof.summary()
     mm = {k: v for k, v in agg.items() if k.startswith("k_")}
     dom = max(mm, key=lambda k_: mm[k_][2])
@@ -201,11 +454,40 @@ def run_encode(args, E, pl, ld, dev):
         t_or = time.perf_counter() - t0
         mine = y.float()[:, :, ob[2]:ob[3], ob[0]:ob[1]]
         den = y.float().abs().max().item()
-        d = (mine - crop.to(mine.device)).abs()
-        parity = {"rel_err_vs_oracle_tile": float(d.max().item() / den), "rms_err_vs_oracle_tile": float((d.pow(2).mean().sqrt() / den).item()), "tile": pick,
+        crop = crop.to(mine.device)
+        d = (mine - crop).abs()
+        parity = {"rel_err_vs_oracle_tile": float(d.max().item() / den), "rms_err_vs_oracle_tile": float((d.pow(2).mean().sqrt() / den).item()),
+                  "rel_l2_vs_oracle_tile": err_metrics(mine, crop)[2], "tile": pick,
                   "pixel_in_bbox": ins[pick], "latent_out_bbox": ob, "tolerance": 1e-3,
                   "what": f"tile {pick} of {len(ins)} of the TIMED image: the engine's moments vs the oracle's encode of the same tile with its own estimator "
                           f"statistics (torch fp32 on this GPU, {t_or:.0f} s); relative to the output's absolute maximum"}
+    # parity on TRAINED-LIKE statistics (hostsim/ldm_decoder.py: apply_stress on the ENCODER): the assembled encode of a 4096 x 4096 image at the same
+    # encoder tile (2 x 2 tiles of ~2080^2 px), default precision and the strict-fp32 engine against the oracle on this GPU (untimed)
+    if not args.no_stress_pass and not args.slow_vae:
+        from oracle import gpu_reference as gr
+        del x, y
+        torch.cuda.empty_cache()
+        enc_s = ld.make_encoder(0, stress=8).to(dev)
+        enc_s.original_forward = enc_s.forward
+        xs_ = torch.randn(1, 3, 4096, 4096, generator=torch.Generator().manual_seed(5)).to(dev)
+        t0 = time.perf_counter()
+        ref = quiet(lambda: gr.tiled_forward_gpu(enc_s, xs_, tile, True, is_decoder=False)).float().cpu()
+        t_or = time.perf_counter() - t0
+        torch.cuda.empty_cache()
+        hook_s = pl.tilevae.VAEHook(enc_s, tile, is_decoder=False, fast_decoder=False, fast_encoder=True, color_fix=False)
+        out = quiet(lambda: hook_s(xs_)).float().cpu()
+        try:
+            E.set_precision(E.PRECISION_F32)
+            out32 = quiet(lambda: hook_s(xs_)).float().cpu()
+        finally:
+            E.set_precision(E.PRECISION_BF16X3)
+        parity = parity or {"tolerance": 1e-3}
+        e, e32 = err_metrics(out, ref), err_metrics(out32, ref)
+        parity.update({"rel_err_vs_oracle_stress": e[0], "rms_err_vs_oracle_stress": e[1], "rel_l2_vs_oracle_stress": e[2],
+                       "rel_err_vs_oracle_stress_f32_engine": e32[0], "rel_l2_vs_oracle_stress_f32_engine": e32[2],
+                       "stress_what": f"assembled ENCODE of a 4096x4096 image at encoder tile {tile} (fast mode) of the trained-like 'stress' encoder (hostsim/ldm_decoder.py: "
+                                      f"apply_stress): default precision and the strict-fp32 engine vs the oracle on torch fp32 on this GPU ({t_or:.0f} s); bar 2e-4",
+                       "stress_recipe": getattr(enc_s, "stress_info", None)})
     return {"metric": "latent-px/sec tiled-VAE-encode, 8K image", "value": round(lat / (ms * 1e-3), 1), "unit": "latent-px/s", "n_gpus": 1, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if E.get_precision() == E.PRECISION_F32 else "bf16x3+f32", "data": "synthetic",
@@ -214,16 +496,156 @@ def run_encode(args, E, pl, ld, dev):
             "roofline": roofline, "parity": parity, "cpu_baseline": None,
             "note": "companion line of the ENCODE direction (SURVEY section 8 f1); the headline metric of BASELINE.json is the default run"}
 
+def run_single_process(args):
+    """`--gpus N --single-process`: the N-device flow inside ONE process -- the only shape an A1111 webui can use ("must be
+    single-process multi-device").  Blend: mdtile.Shard(dev_ids) (mdtile_shard_init: one RCCL communicator per device via ncclCommInitAll, or
+    peer copies) + mdtile.sharding.ShardedBlend (row bands of tiles per device, halo exchange of the overlap rows behind the C ABI, finalize
+    per band).  Decode: VAEHook.devices -- estimator on the first device, tiles dealt to the devices by area, one stream and one packed copy
+    of the weights per device, the decoded rectangles copied into the first device's canvas inside the step.  One Python thread issues
+    every launch; the devices run asynchronously.  On a box with fewer than N GPUs cuda:0 is listed N times (functional run)."""
+    visible = torch.cuda.device_count()
+    n = args.gpus
+    shared_device = visible < n
+    devs = [0] * n if shared_device else list(range(n))
+    torch.cuda.set_device(0)
+    dev0 = torch.device("cuda", 0)
+    import __graft_entry__ as ge
+    ge.build()
+    from hostsim import stub_host as sh, ldm_decoder as ld
+    sh.install(dev0)
+    sh.set_device(dev0)
+    pl = sh.load_plugin()
+    E = pl.engine
+    from mdtile import sharding
+    try:
+        shard = E.Shard(dev_ids=devs)
+    except E.MdtileError as e:      # RCCL could not build the in-process communicators: peer copies carry the same calls
+        print(f"[bench] mdtile_shard_init over RCCL failed ({e}); retrying on the copy transport", file=sys.stderr)
+        os.environ["MDTILE_SHARD_TRANSPORT"] = "copy"
+        shard = E.Shard(dev_ids=devs)
+    transport = ("rccl (ncclCommInitAll inside the process, C ABI)" if shard.rccl else "copy (peer hipMemcpyAsync + events, C ABI)") + \
+        (" -- cuda:0 listed %d times: functional run" % n if shared_device else "")
+    shard.selfcheck()
+    L, N, C = args.latent, 2, 4
+    method = E.METHOD_MD if args.method == "md" else E.METHOD_MOD
+    sb = sharding.ShardedBlend(shard, L, L, args.tile, args.tile, args.overlap, args.tile_bs, method)
+    plan = sb.local[0]["plan"]
+    x_cpu = torch.randn(N, C, L, L, generator=torch.Generator(device="cpu").manual_seed(0))
+    full = torch.randn(plan.num_tiles * N, C, plan.tile_h, plan.tile_w, generator=torch.Generator(device="cpu").manual_seed(1))
+    xs, pre = [], []
+    for i, d in enumerate(devs):
+        b = sb.bands[i]
+        xs.append(x_cpu.to(torch.device("cuda", d)))
+        pre.append(None if b.empty else full[b.tile_lo * N:b.tile_hi * N].to(torch.device("cuda", d)))
+    del full
+    order = [i for i in range(n) if not sb.bands[i].empty]
+    cursor = [0]
+
+    def tile_fn(x_tiles):          # the pre-generated model outputs of the band whose turn it is (ShardedBlend.step walks the local ranks in order)
+        i = order[cursor[0] % len(order)]
+        cursor[0] += 1
+        return pre[i]
+
+    def blend_eval():
+        cursor[0] = 0
+        return sb.step(xs, tile_fn)
+
+    hook = z = dec = None
+    if not args.no_vae:
+        if args.slow_vae:
+            raise SystemExit("--single-process decodes in fast mode (VAEHook.devices needs no collective: the frozen statistics are computed once and copied)")
+        dec = ld.make_decoder(0).to(dev0)
+        dec.original_forward = dec.forward
+        hook = pl.tilevae.VAEHook(dec, args.vae_tile, is_decoder=True, fast_decoder=True, fast_encoder=False, color_fix=False)
+        hook.devices = devs
+        z = torch.randn(1, 4, L, L, generator=torch.Generator(device="cpu").manual_seed(2)).to(dev0)
+
+    def sync_all():
+        for d in sorted(set(devs)):
+            torch.cuda.synchronize(d)
+
+    def step():
+        for _ in range(args.evals):
+            blend_eval()
+        return hook(z) if hook is not None else None
+
+    def timed(fn, k):
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        sync_all()
+        return (time.perf_counter() - t0) / k
+
+    for _ in range(args.warmup):
+        _quiet(step)
+    elapsed = timed(lambda: _quiet(step), args.steps)
+    t_blend = timed(blend_eval, args.evals)
+    t_vae = timed(lambda: _quiet(lambda: hook(z)), 1) if hook is not None else None
+    check = None
+    if hook is not None:
+        # the assembled image of the N-device sweep against the plain one-device sweep of the same latent (same kernels, same frozen
+        # statistics: bit for bit) -- and the sharded blend's canvas rows against the one-device blend
+        img = _quiet(lambda: hook(z)).float()
+        hook.devices = None
+        ref = _quiet(lambda: hook(z)).float()
+        hook.devices = devs
+        check = {"assembled_image_bit_identical_to_one_device": bool(torch.equal(img, ref)),
+                 "assembled_image_rel_err_vs_one_device": float((img - ref).abs().max().item() / ref.abs().max().item()), "image_shape": list(img.shape)}
+        del img, ref
+    kw = dict(weights=sb.local[0]["weights"]) if method == E.METHOD_MD else dict(tile_w=sb.local[0]["tile_wt"], rescale=sb.local[0]["rescale"])
+    with torch.cuda.device(dev0):
+        full0 = torch.randn(plan.num_tiles * N, C, plan.tile_h, plan.tile_w, generator=torch.Generator(device="cpu").manual_seed(1)).to(dev0)
+        one = E.blend(plan, method, [full0], N, C, packed=True, **kw)
+    outs = blend_eval()
+    sync_all()
+    worst = 0.0
+    for i in order:
+        b = sb.bands[i]
+        worst = max(worst, float((outs[i][:, :, b.row_lo:b.row_hi].to(dev0) - one[:, :, b.row_lo:b.row_hi]).abs().max().item()))
+    check = dict(check or {}, sharded_blend_max_abs_diff_vs_one_device=worst)
+    del full0, one
+    value = L * L / elapsed
+    print(json.dumps({
+        "metric": "latent-px/sec tile-blend+VAE-decode, 8K image", "value": round(value, 1), "unit": "latent-px/s", "n_gpus": n, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32" if E.get_precision() == E.PRECISION_F32 else "bf16x3+f32", "data": "synthetic",
+        "config": {"workload": f"{'SDXL ' if L == 1024 else ''}{8 * L}x{8 * L} (latent {L}x{L}): {args.evals} x [tile gather + {'MultiDiffusion' if args.method == 'md' else 'Mixture-of-Diffusers'} "
+                               f"blend, {plan.num_tiles} tiles {plan.tile_w}x{plan.tile_h} overlap {plan.overlap}, N=2,C=4] + "
+                               + ("no VAE" if hook is None else f"tiled VAE decode (tile {args.vae_tile}, fast mode, SD decoder ch=128, random weights)"),
+                   "latent": [L, L], "tile": [plan.tile_w, plan.tile_h], "overlap": plan.overlap, "evals": args.evals, "vae_tile": None if hook is None else args.vae_tile,
+                   "sharding": f"ONE process, {n} devices: tile-row bands + halo exchange (mdtile.Shard / ShardedBlend); VAE tiles dealt to the devices by area "
+                               "(VAEHook.devices), estimator on the first device, rectangles copied to the first device inside the step"},
+        "process_model": "single-process multi-device (mdtile_shard_init + VAEHook.devices)", "devices": devs, "devices_visible": visible,
+        "stage_ms": {"blend_eval": round(t_blend * 1e3, 4), "vae_decode": None if t_vae is None else round(t_vae * 1e3, 2)},
+        "transport": transport, "debug_check": check, "roofline": None, "cpu_baseline": None,
+        "note": "per-kernel roofline, parity legs and cpu_baseline are on the N = 1 line; this line times the single-process form of the N-device flow"}))
+    shard.destroy()
+
 
 def main():
     args = parse()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback path exists in the product)")
+    if args.single_process and args.gpus > 1:
+        if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
+            raise SystemExit("--single-process drives every device from ONE process: do not start it under torch.distributed.run")
+        return run_single_process(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher environment: this process becomes the launcher (VERDICT round 5: the bare command must not die before touching a GPU)
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback path exists in the product)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus {args.gpus}` (bench.py spawns its ranks) or under "
+                         f"torch.distributed.run --nproc-per-node {args.gpus}")
+    devices_visible = torch.cuda.device_count()
+    if world > 1 and devices_visible < world and not args.debug_single_device:
+        # fewer GPUs than ranks (every rank sees the same count): the N-rank flow still runs, with all ranks on cuda:0 over gloo
+        args.debug_single_device = True
+        if rank == 0:
+            print(f"[bench] {devices_visible} GPU(s) visible for {world} ranks: every rank uses cuda:0 and gloo (functional run)", file=sys.stderr)
     if args.debug_single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -441,6 +863,22 @@ def main():
                                    "frac": round(cold[1] / cold[2] / 1e9 / HBM_PEAK_GBS, 4),
                                    "what": "8 rotating sets of tile outputs + canvases (610 MB > 256 MiB Infinity Cache): every read comes from HBM"}
             del rot
+            # (b') the FLOOR beside it: a plain 16-byte-per-lane copy that moves the same number of bytes (half read, half written), cold the
+            #      same way (8 rotating source / destination pairs, 20 back-to-back launches per event pair, median of 5 rounds) -- what this
+            #      chip gives a single ~80 MB launch with no table hop, no tile walk, no arithmetic
+            half = (blend_bytes // 2 + 4095) // 4096 * 4096
+            cp = []
+            for i in range(8):
+                s_i = torch.randn(half // 4, device=dev)
+                d_i = torch.empty(half // 4, device=dev)
+                cp.append(E.StreamCopyCall(s_i, d_i))
+            t_cp = time_launches(cp)
+            blend_extra["copy_floor_us"] = round(t_cp * 1e6, 2)
+            blend_extra["copy_floor_GBps"] = round(2 * half / t_cp / 1e9, 1)
+            blend_extra["frac_of_copy_floor"] = round(t_cp / (cold[2] / 20), 4)
+            blend_extra["copy_floor_what"] = (f"mdtile_stream_copy of {half} B -> {half} B (= the blend's {blend_bytes} algorithmic bytes), 8 rotating buffer pairs, timed like "
+                                              "`achieved`; frac_of_copy_floor = copy time / blend time")
+            del cp
             # (c) fp16 I/O (the webui's default dtype; fp32 accumulation inside the kernel): half the tile / canvas bytes
             th16 = tile_out.half()
             o16 = torch.empty(N, C, L, L, device=dev, dtype=torch.float16)
@@ -452,59 +890,8 @@ def main():
                                   "bytes_per_launch": int(bytes16), "residency": "Infinity-Cache resident (static buffers)"}
             del th16, o16, call16
         if hook is not None:
-            orig_call = E.PackedConv.__call__
-            orig_rec = E.PackedConv.call_rec
-            subpixel = E.get_precision() == E.PRECISION_BF16X3
-
-            def timed_call(self, x, residual=None, upsample2x=False, token_major=False, exact=False, pre_gn=None, **kw):
-                # the fp32 hand-over kernels (estimator pass, 1x1 convs, conv_in): tagged by kernel family
-                B, cin, H, W = x.shape
-                if upsample2x:
-                    H, W = 2 * H, 2 * W
-                flops = 2.0 * B * H * W * self.cout * cin * self.ksize * self.ksize
-                bf = subpixel and not exact and not token_major and cin % 16 == 0
-                if self.ksize == 1:
-                    tag = "k_conv1x1_stream<*> / k_conv1x1_bf16x3<*>" if (bf and cin % 32 == 0) else "k_conv<1,*> (exact fp32 MFMA)"
-                elif upsample2x and bf:
-                    flops *= 4.0 / 9.0      # sub-pixel form of nearest-2x + 3x3 conv: four 2x2 convs -> 4/9 of the MACs are EXECUTED
-                    tag = "k_upconv_bf16x3<*> (fp32 hand-over)"
-                else:
-                    tag = "k_conv3x3_bf16x3<*> (fp32 hand-over)" if bf else "k_conv3x3_fewcin<*> (conv_in, fp32 FMA)" if cin in (3, 4) and not token_major \
-                        else "k_conv<3,*> (exact fp32 MFMA)"
-                return prof.wrap(tag, flops, lambda: orig_call(self, x, residual, upsample2x, token_major, exact, pre_gn, **kw))
-
-            def timed_rec(self, x, residual=None, upsample2x=False, want_f32=True, want_rec=False, rec_coef=None, window=None, family=0, **kw):
-                # record kernels: the tag IS the kernel symbol mdtile_conv2d_rec launches (csrc/vae_conv_rec.hip, dispatch at the end)
-                B, cin, H, W = x.shape
-                if window is not None:
-                    H, W = window[2], window[3]      # live-window narrowing: the flops EXECUTED are those of the window
-                if upsample2x:
-                    H, W = 2 * H, 2 * W
-                flops = 2.0 * B * H * W * self.cout * cin * 9
-                tag = "k_conv3x3_rec<2, 2, 4>" if self.cout % 128 == 0 else "k_conv3x3_rec<1, 1, 2>"
-                if upsample2x:
-                    flops *= 4.0 / 9.0
-                    tag = "k_upconv_rec"
-                return prof.wrap(tag, flops, lambda: orig_rec(self, x, residual, upsample2x, want_f32, want_rec, rec_coef, window, family, **kw))
-
-            orig_attn = E.vae_attn
-
-            def timed_attn(q, k, v, scale, exact=False, v_channel_major=False):
-                B, Cc, T = q.shape
-                return prof.wrap("k_attn_bf16x3<512>" if subpixel and not exact else "k_attn<*> (exact fp32 MFMA)", 4.0 * B * T * T * Cc,
-                                 lambda: orig_attn(q, k, v, scale, exact, v_channel_major))
-
-            E.PackedConv.__call__ = timed_call
-            E.PackedConv.call_rec = timed_rec
-            E.vae_attn = timed_attn
-            builtins.print = lambda *a, **k: None
-            try:
-                hook(z)
-            finally:
-                builtins.print = _print
-                E.PackedConv.__call__ = orig_call
-                E.PackedConv.call_rec = orig_rec
-                E.vae_attn = orig_attn
+            with Instrument(E, prof):
+                _quiet(lambda: hook(z))
         agg = prof.summary()
         if "blend" in agg:
             n, work, secs = agg["blend"]
@@ -623,6 +1010,7 @@ def main():
         value_f32 = L * L / (ms_f32 * 1e-3)
         den = img32.abs().max().item()
         parity = {"rel_err_vs_f32": float((img - img32).abs().max().item() / den), "rms_err_vs_f32": float(((img - img32).pow(2).mean().sqrt() / den).item()),
+                  "rel_l2_vs_f32": float(((img - img32).double().pow(2).sum().sqrt() / img32.double().pow(2).sum().sqrt()).item()),
                   "what": "whole 8K image of the timed configuration: default split-bf16 engine vs the engine's exact-fp32 MFMA kernels (mdtile_set_precision), same z and weights",
                   "tolerance": 1e-3}
         del img, img32
@@ -649,6 +1037,8 @@ def main():
         parity = parity or {"tolerance": 1e-3}
         parity.update({"rel_err_vs_oracle": float((out - ref).abs().max().item() / den),
                        "rms_err_vs_oracle": float(((out - ref).pow(2).mean().sqrt() / den).item()),
+                       "rel_l2_vs_oracle": err_metrics(out, ref)[2],
+                       "error_norms": "rel_err_* = max|d| / max|ref| (range-normalised), rms_err_* = rms(d) / max|ref|, rel_l2_* = ||d||_2 / ||ref||_2",
                        "oracle_what": f"assembled decode of a 512x512 latent (BASELINE cfg3) at decoder tile {args.vae_tile}, {'slow' if args.slow_vae else 'fast'} mode: "
                                       "engine (default precision) vs oracle/vae_oracle.py run on this GPU via torch fp32 conv / bmm (oracle/gpu_reference.py), "
                                       f"{t_oracle:.0f} s; the tile shapes are the four of the 8K decode; also tests/test_gpu_vae_large.py"})
@@ -677,8 +1067,8 @@ def main():
                 mine = img8[:, :, ob[2]:ob[3], ob[0]:ob[1]]
                 d = (mine - crop.to(mine.device)).abs()
                 per_tile[name] = {"tile": t, "latent_in_bbox": ins8[t], "image_out_bbox": ob, "rel_err": float(d.max().item() / den8),
-                                  "rms_err": float((d.pow(2).mean().sqrt() / den8).item())}
-            parity.update({"rel_err_vs_oracle_8k_interior": per_tile["interior"]["rel_err"],
+                                  "rms_err": float((d.pow(2).mean().sqrt() / den8).item()), "rel_l2": err_metrics(mine, crop.to(mine.device))[2]}
+            parity.update({"rel_err_vs_oracle_8k_interior": per_tile["interior"]["rel_err"], "rel_l2_vs_oracle_8k_interior": per_tile["interior"]["rel_l2"],
                            "rel_err_vs_oracle_8k_tiles": per_tile,
                            "oracle_8k_what": f"tiles of the TIMED 8192x8192 image (live windows {'on' if pl.tilevae.LIVE_WINDOW else 'off'}) against the oracle's decode of the same "
                                              f"tiles of the same latent with its own estimator statistics (torch fp32 on this GPU, {t_or8:.0f} s); "
@@ -716,6 +1106,7 @@ def main():
         parity = parity or {"tolerance": 1e-3}
         parity.update({"rel_err_vs_oracle_stress": float((out - ref).abs().max().item() / den),
                        "rms_err_vs_oracle_stress": float(((out - ref).pow(2).mean().sqrt() / den).item()),
+                       "rel_l2_vs_oracle_stress": err_metrics(out, ref)[2], "rel_l2_vs_oracle_stress_f32_engine": err_metrics(out32, ref)[2],
                        "rel_err_vs_oracle_stress_f32_engine": float((out32 - ref).abs().max().item() / den),
                        "stress_what": f"assembled decode of a 512x512 latent (BASELINE cfg3) at decoder tile {args.vae_tile}, {'slow' if args.slow_vae else 'fast'} mode, of the "
                                       "trained-like 'stress' decoder (hostsim/ldm_decoder.py: apply_stress): default precision and the strict-fp32 engine vs the oracle on "
@@ -723,6 +1114,15 @@ def main():
                        "stress_recipe": getattr(dec_s, "stress_info", None)})
         del ref, out, out32, hook_s, dec_s
         torch.cuda.empty_cache()
+
+    # ------------------------------------------------------------------ the other configurations of SURVEY 8(d), untimed for the headline
+    companions = None
+    if rank == 0 and world == 1 and hook is not None and not args.no_companions and not args.slow_vae and L == 1024 and E.get_precision() == E.PRECISION_BF16X3:
+        try:
+            companions = run_companions(args, E, pl, ld, dev, dec, z, t_blend_eval)
+        except Exception as e:      # noqa: BLE001 -- a companion figure must never cost the headline line
+            companions = {"error": repr(e)}
+            torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ CPU baseline (oracle = port of the reference), rank 0, N=1
     cpu_baseline = None
@@ -797,7 +1197,10 @@ def main():
             "value_f32": None if value_f32 is None else round(value_f32, 1), "ms_per_step_f32": None if ms_f32 is None else round(ms_f32, 2),
             "parity": parity,
             "roofline": roofline, "roofline_blend": roofline_blend, "roofline_blend_f16": roofline_blend_f16, "cpu_baseline": cpu_baseline,
+            "companions": companions,
             "transport": transport, "debug_check": debug_check,
+            "launcher": os.environ.get("MDTILE_BENCH_LAUNCHER", "torch.distributed.run" if world > 1 else "none (one process, one device)"),
+            "process_model": "one process per GPU" if world > 1 else "single process", "devices_visible": devices_visible,
         }
         print(json.dumps(out))
     if world > 1:

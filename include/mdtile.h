@@ -114,6 +114,11 @@ int mdtile_gather_range(const mdtile_plan* plan, int dtype, int N, int C, const 
 /* Arbitrary-rect gather for custom regions: `x_in[bbox.slicer]` (multidiffusion.py:184, mixtureofdiffusers.py:140). */
 int mdtile_gather_rect(int dtype, int N, int C, int W, int H, const void* d_x_in, int x, int y, int w, int h,
                        void* d_out, mdtile_stream_t stream);
+/* Plain streaming copy of `bytes` bytes (16-byte accesses, one KiB per wave-instruction; both pointers 16-byte aligned, bytes % 16 == 0),
+ * launched like the blend (one grid over the buffer, same stream).  Nothing upstream corresponds to it: it is the measurement
+ * floor bench.py prints beside the blend kernel (`roofline_blend.copy_floor_us`: the same number of HBM bytes moved with no
+ * table hop, no tile walk and no arithmetic), and a device-to-device copy for callers that have no torch at hand. */
+int mdtile_stream_copy(const void* d_src, void* d_dst, size_t bytes, mdtile_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------------------
  * Overlap blend (K3..K7), gather-formulated: one thread owns output pixels, sums the covering tile values in

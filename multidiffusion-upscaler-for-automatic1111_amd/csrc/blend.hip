@@ -419,6 +419,18 @@ __global__ __launch_bounds__(256) void k_gather_rect(const T* __restrict__ x_in,
     out[(size_t)plane * w * h + idx] = x_in[((size_t)plane * H + y0 + y) * W + x0 + x];
 }
 
+// the blend's measurement floor (mdtile_stream_copy): every thread moves 4 x 16 bytes, a wave 4 x 1 KiB runs a block-stride apart
+__global__ __launch_bounds__(256) void k_stream_copy(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+    const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    uint4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (base + i * 256 < n16) v[i] = src[base + i * 256];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (base + i * 256 < n16) dst[base + i * 256] = v[i];
+}
+
 // (planes per thread, candidates per chunk).  PP must divide N*C; MDTILE_BLEND_CFG="PP,G" overrides the default (probing).
 template <typename T, int PP, int G>
 void launch_blend_cfg(const BlendParams& P, int method, hipStream_t s) {
@@ -612,6 +624,17 @@ extern "C" int mdtile_gather_range(const mdtile_plan* p, int dtype, int N, int C
     if (tile_lo == tile_hi) return MDTILE_OK;
     void* ptrs[1] = {d_packed};
     return gather_common(p, dtype, N, C, d_x_in, ptrs, 1, tile_lo, tile_hi, 1, as_stream(stream));
+}
+
+extern "C" int mdtile_stream_copy(const void* d_src, void* d_dst, size_t bytes, mdtile_stream_t stream) {
+    MDT_CHECK_ARG(d_src && d_dst, "mdtile_stream_copy: null argument");
+    MDT_CHECK_ARG(bytes % 16 == 0 && ((uintptr_t)d_src & 15) == 0 && ((uintptr_t)d_dst & 15) == 0, "mdtile_stream_copy: pointers and size must be multiples of 16 bytes");
+    if (bytes == 0) return MDTILE_OK;
+    const size_t n16 = bytes / 16;
+    MDT_CHECK_ARG(n16 <= (size_t)0x7fffffff * 1024, "mdtile_stream_copy: %zu bytes in one launch", bytes);
+    hipLaunchKernelGGL(k_stream_copy, dim3((unsigned)((n16 + 1023) / 1024)), dim3(256), 0, as_stream(stream), (const uint4*)d_src, (uint4*)d_dst, n16);
+    MDT_LAUNCH_CHECK();
+    return MDTILE_OK;
 }
 
 extern "C" int mdtile_gather_rect(int dtype, int N, int C, int W, int H, const void* d_x_in, int x, int y, int w, int h,

@@ -72,6 +72,7 @@ _SIGNATURES = {
     "mdtile_gather_all": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, POINTER(c_void_p), c_int, c_void_p]),
     "mdtile_gather_range": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "mdtile_gather_rect": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "mdtile_stream_copy": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "mdtile_blend": (c_int, [c_void_p, POINTER(_BlendArgs), POINTER(c_void_p), c_int, POINTER(_Region), c_int, c_void_p]),
     "mdtile_blend_finalize": (c_int, [c_void_p, POINTER(_BlendArgs), c_void_p, POINTER(_Region), c_int, c_void_p]),
     "mdtile_region_noise": (c_int, [c_void_p, c_int, c_int, c_int, c_int, POINTER(_Region), c_int, c_void_p]),
@@ -500,6 +501,32 @@ def blend(plan: Plan, method: int, batch_out: Sequence[torch.Tensor], N: int, C:
     """One fused launch replacing the scatter/normalise/feather op sequence of sample_one_step / apply_model_hijack."""
     return BlendCall(plan, method, batch_out, N, C, weights=weights, tile_w=tile_w, rescale=rescale, regions=regions, out=out, dtype=dtype,
                      device=device, partial=partial, tile_range=tile_range, row_range=row_range, packed=packed)()
+
+
+class StreamCopyCall:
+    """Marshalled mdtile_stream_copy (src -> dst, same size, contiguous, 16-byte aligned): the measurement floor bench.py times beside the
+    blend kernel, launched the same way (see BlendCall)."""
+
+    __slots__ = ("_args", "_fn", "_keep")
+
+    def __init__(self, src: torch.Tensor, dst: torch.Tensor):
+        _dev_tensor(src, "src")
+        _dev_tensor(dst, "dst")
+        nbytes = src.numel() * src.element_size()
+        assert nbytes == dst.numel() * dst.element_size() and nbytes % 16 == 0
+        self._args = (c_void_p(src.data_ptr()), c_void_p(dst.data_ptr()), c_size_t(nbytes))
+        self._keep = (src, dst)
+        self._fn = lib().mdtile_stream_copy
+
+    def __call__(self) -> None:
+        rc = self._fn(*self._args, _stream())
+        if rc != OK:
+            _check(rc, "mdtile_stream_copy")
+
+
+def stream_copy(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    StreamCopyCall(src, dst)()
+    return dst
 
 
 class GatherRangeCall:

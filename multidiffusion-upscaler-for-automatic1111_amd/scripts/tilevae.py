@@ -287,7 +287,7 @@ class VAEHook:
         # ranks' tile rectangles travel to it in one grouped exchange; None leaves every rank with only its own tiles filled in
         self.gather_to: Optional[int] = None
         # single-process multi-device decode (what a webui process can use): CUDA device indices, e.g. [0, 1, 2, 3]; the tiles are
-        # dealt round-robin to the devices, each with its own copy of the packed weights; fast mode only (no collective needed:
+        # dealt to the devices by area, each with its own copy of the packed weights; fast mode only (no collective needed:
         # the frozen statistics are computed once and copied).  A device may be listed twice (functional runs on one GPU).
         self.devices: Optional[List[int]] = None
         self._dev_programs = {}
@@ -622,9 +622,11 @@ class VAEHook:
         return self._dev_programs[index]
 
     def _multi_device_sweep(self, z: Tensor, steps0: List[Step], frozen, in_bboxes, out_bboxes, dtype, t0) -> Tensor:
-        """Fast mode on several devices of ONE process: tile i runs on devices[i % n] (own stream, own packed weights, the frozen
-        statistics copied over); launches are asynchronous, so one Python thread keeps all devices busy.  The output tiles are
-        disjoint (out_bboxes never overlap): each device crops into its own canvas and its rectangles are copied to the first
+        """Fast mode on several devices of ONE process: the tiles are dealt to the devices by area (mdtile/sharding.py: deal_tiles, the deal of
+        the process-per-GPU path), each device with its own stream, its own packed weights and a copy of the frozen statistics; launches
+        are asynchronous, so one Python thread keeps all devices busy -- the tiles are issued device by device in rounds (every device's
+        first tile, then every device's second ...), so no device waits for the host to finish another device's list.  The output tiles
+        are disjoint (out_bboxes never overlap): each device crops into its own canvas and its rectangles are copied to the first
         device at the end (peer copies over xGMI)."""
         E = self.engine
         N, _, height, width = z.shape
@@ -638,10 +640,13 @@ class VAEHook:
                 fz = [(v.to(d), m.to(d)) for (v, m) in frozen]
                 coefs = [E.gn_coeffs(m, v, steps[i].norm[0], steps[i].norm[1], steps[i].channels, 32, 1e-6) for i, (v, m) in zip(norm_idx, fz)]
                 per.append(dict(steps=steps, frozen=fz, coefs=coefs, z=z.to(d), result=None, flags=[], mine=[]))
-        for i in range(len(in_bboxes)):
+        from mdtile import sharding as _sh
+        owner = _sh.deal_tiles(in_bboxes, len(devs))
+        lists = [[i for i in range(len(in_bboxes)) if owner[i] == k] for k in range(len(devs))]
+        issue = [(lst[r], k) for r in range(max(len(lst) for lst in lists)) for k, lst in enumerate(lists) if r < len(lst)]
+        for i, k in issue:
             if state.interrupted:
                 break
-            k = i % len(devs)
             L, d = per[k], devs[k]
             with torch.cuda.device(d):
                 b = in_bboxes[i]

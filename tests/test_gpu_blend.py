@@ -230,3 +230,16 @@ def test_region_noise_hijack_bit_exact(plugin, cuda, dtype):
     ref = bo.region_noise(org.to(dtype).float(), REGION_NOISE)
     assert torch.equal(got.float().cpu(), ref.to(dtype).float())
     assert [info[f"Region {i + 1}"]["seed"] for i in range(len(REGION_NOISE))] == [r[5] for r in REGION_NOISE]
+
+
+def test_stream_copy_is_a_copy(plugin, cuda):
+    """mdtile_stream_copy (the measurement floor bench.py prints beside the blend kernel): bit-exact copy, ragged tail of the 4 KiB block
+    stride included; misaligned / odd-sized requests are refused."""
+    E = plugin.engine
+    for n in (4, 1024, 1024 * 1024 + 12, 10 * 1024 * 1024 + 4):
+        src = torch.randn(n, device=cuda)
+        dst = torch.zeros(n + 8, device=cuda)
+        E.stream_copy(src, dst[:n])
+        assert torch.equal(dst[:n], src) and not dst[n:].any()
+    with pytest.raises(E.MdtileError):
+        E.lib().mdtile_stream_copy(src.data_ptr() + 4, dst.data_ptr(), 64, None)

@@ -300,6 +300,47 @@ def test_bench_flow_n_ranks_on_one_device_matches_the_single_rank_image(cuda, wo
     assert d["debug_check"]["assembled_image_rel_err_vs_single_rank"] < 1e-4, d["debug_check"]
 
 
+_SMALL = ["--steps", "1", "--warmup", "0", "--latent", "256", "--vae-tile", "64", "--evals", "2", "--no-cpu-baseline", "--no-profile-pass", "--no-f32-pass",
+          "--no-whole-tile-pass", "--no-oracle-pass", "--no-stress-pass", "--no-companions"]
+
+
+def _bench_line(argv, timeout=900):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MDTILE_BENCH_LAUNCHER")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=timeout, cwd=root)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+    return json.loads(lines[0])
+
+
+def test_bare_bench_command_launches_its_own_ranks(cuda):
+    """`python bench.py --gpus 2 ...` with NO launcher environment (the shape of the driver's recorded N = 1 command): rc 0, exactly one JSON
+    line, n_gpus = 2, a transport, and rank 0's assembled image equal to the single-rank decode.  On this one-GPU box the two ranks share
+    cuda:0 (bench.py adds --debug-single-device itself when fewer GPUs than ranks are visible)."""
+    d = _bench_line(["--gpus", "2"] + _SMALL)
+    assert d["n_gpus"] == 2 and d["transport"] and "bench.py" in d["launcher"], d
+    assert d["process_model"] == "one process per GPU" and d["devices_visible"] >= 1
+    if d["devices_visible"] < 2:
+        assert d["debug_check"] is not None and d["debug_check"]["assembled_image_rel_err_vs_single_rank"] < 1e-4, d["debug_check"]
+
+
+@pytest.mark.parametrize("n", [2, 8])
+def test_single_process_bench_form(cuda, n):
+    """`python bench.py --gpus N --single-process`: mdtile.Shard(dev_ids) + ShardedBlend + VAEHook.devices in ONE process (what a webui can
+    use) -- timed line with n_gpus = N, the assembled image bit-identical to the one-device sweep, the sharded blend equal to the
+    one-device blend on every band's rows (one-GPU box: cuda:0 listed N times, copy transport)."""
+    d = _bench_line(["--gpus", str(n), "--single-process"] + _SMALL)
+    assert d["n_gpus"] == n and d["process_model"].startswith("single-process") and len(d["devices"]) == n, d
+    assert d["transport"].startswith(("rccl", "copy")), d["transport"]
+    chk = d["debug_check"]
+    assert chk["assembled_image_bit_identical_to_one_device"] is True and chk["image_shape"] == [1, 3, 2048, 2048], chk
+    assert chk["sharded_blend_max_abs_diff_vs_one_device"] < 1e-5, chk
+
+
 def test_bring_up_probe_is_interruptible(plugin, cuda):
     """mdtile_shard_probe_rank: the rendezvous of ncclCommInitRank on a NON-BLOCKING communicator, polled under a deadline and aborted on it.
     (1) a one-rank probe comes up; (2) rank 0 of a TWO-rank communicator whose peer never shows up gives up on the deadline with an error --

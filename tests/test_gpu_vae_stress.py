@@ -106,3 +106,50 @@ def test_stress_attention_alone(plugin, cuda, logit_std):
     err_x = _rel(E.vae_attn(q, k, vt, scale, exact=True).double(), ref)
     print(f"attention at logit std {logit_std}: bf16x3 {err:.2e}, exact {err_x:.2e}")
     assert err < TOL_DEFAULT and err_x < TOL_F32
+
+
+# ---- the ENCODE direction on the same trained-like statistics (f1's parity rested on default-init weights) -------------------
+# upstream: scripts/tilevae.py:155-171 (encoder task queue with the stride-2 Downsample convs), :492-496 (color_fix: statistics frozen only
+# up to the first downsample, the rest pooled across tiles), :507-656 (the tile sweep with is_decoder=False, pad 32)
+@pytest.mark.parametrize("fast,color_fix,logit_std", [(True, False, 8), (True, False, 16), (False, False, 8), (True, True, 8)],
+                         ids=["fast-std8", "fast-std16", "slow-std8", "color_fix-std8"])
+def test_stress_encode_vs_cpu_oracle(plugin, cuda, fast, color_fix, logit_std):
+    """Full-width stress ENCODER, 168 x 136 image, encoder tile 64 (pad 32: 3 x 3 tiles of <= 128 px) against the CPU oracle: fast mode, slow mode
+    (every norm pooled -- incl. the narrow conv_out, cout 8, behind the pooled norm_out on the record path) and color_fix, default precision and
+    the strict-fp32 engine."""
+    E = plugin.engine
+    enc_cpu = ld.make_encoder(7, stress=logit_std)
+    torch.manual_seed(23)
+    x = torch.randn(1, 3, 168, 136)
+    ref = vo.tiled_forward(enc_cpu, x, 64, fast, is_decoder=False, color_fix=color_fix)
+    assert torch.isfinite(ref).all() and ref.shape == (1, 8, 21, 17)
+    enc = ld.make_encoder(7, stress=logit_std).to(cuda)
+    enc.original_forward = enc.forward
+    hook = plugin.tilevae.VAEHook(enc, 64, is_decoder=False, fast_decoder=False, fast_encoder=fast, color_fix=color_fix)
+    out, out32 = _both_precisions(E, hook, x.to(cuda))
+    err, err32 = _rel(out, ref), _rel(out32, ref)
+    l2 = ((out - ref).double().norm() / ref.double().norm()).item()
+    print(f"stress encoder (logit std {logit_std}, fast={fast}, color_fix={color_fix}) tile 64: bf16x3 vs CPU oracle {err:.2e} (rel L2 {l2:.2e}), f32 engine vs CPU oracle {err32:.2e}")
+    assert err < TOL_DEFAULT, f"stress encode, default precision: rel err {err}"
+    assert err32 < TOL_F32, f"stress encode, strict fp32 engine: rel err {err32}"
+
+
+def test_stress_encode_tile_at_upstream_recommended_size_vs_oracle_on_gpu(plugin, cuda):
+    """One 3072-class tile of the stress encoder (a 6144 x 6144 image at encoder tile 3072 = 2 x 2 tiles of 3104^2 px, T = 150 544-token attention,
+    fast mode) against the oracle's encode of the same tile on the GPU: default precision and the strict-fp32 engine."""
+    E = plugin.engine
+    enc = ld.make_encoder(0, stress=8).to(cuda)
+    enc.original_forward = enc.forward
+    x = torch.randn(1, 3, 6144, 6144, generator=torch.Generator().manual_seed(1)).to(cuda)
+    (ob, crop), = gr.tiled_forward_gpu(enc, x, 3072, True, is_decoder=False, only_tiles=[2])
+    crop = crop.cpu()
+    assert torch.isfinite(crop).all()
+    torch.cuda.empty_cache()
+    hook = plugin.tilevae.VAEHook(enc, 3072, is_decoder=False, fast_decoder=False, fast_encoder=True, color_fix=False)
+    out, out32 = _both_precisions(E, hook, x)
+    den = out32.abs().max().item()
+    cut = lambda t: t[:, :, ob[2]:ob[3], ob[0]:ob[1]]      # noqa: E731
+    err = (cut(out) - crop).abs().max().item() / den
+    err32 = (cut(out32) - crop).abs().max().item() / den
+    print(f"stress encoder, 6144^2 at encoder tile 3072, tile 2 vs the oracle on the GPU: bf16x3 {err:.2e}, f32 engine {err32:.2e}")
+    assert err < TOL_DEFAULT and err32 < TOL_F32
