@@ -139,4 +139,5 @@ struct mdtile_plan {
     //   colquad[x/4] = { first | count << 16 of the tile columns covering ANY of the 4 px, xs[first], xs[first+1], xs[first+2] }
     //   rowinfo[y]   = { first | count << 16 of the tile rows covering y,               ys[first], ys[first+1], ys[first+2] }
     int4 *d_colquad, *d_rowinfo;
+    int nc_max, nr_max;       // most tile columns covering one 4-px quad / most tile rows covering one canvas row (blend kernel dispatch)
 };

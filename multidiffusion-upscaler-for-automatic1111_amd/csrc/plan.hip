@@ -117,6 +117,7 @@ extern "C" mdtile_plan* mdtile_plan_create(int w, int h, int tile_w, int tile_h,
     // non-decreasing and every pixel is covered, so the union is a contiguous index range.
     auto origin3 = [](const std::vector<int>& org, int first, int k) { return first + k < (int)org.size() ? org[first + k] : 0; };
     int* cq = p->h_table + p->quad_off;
+    p->nc_max = p->nr_max = 0;
     for (int xq = 0; xq < W4; ++xq) {
         int first = 1 << 30, last = -1;
         for (int j = 0; j < 4 && 4 * xq + j < w; ++j) {
@@ -127,12 +128,14 @@ extern "C" mdtile_plan* mdtile_plan_create(int w, int h, int tile_w, int tile_h,
         }
         if (last < 0) { first = 0; last = -1; }
         cq[4 * xq + 0] = first | ((last - first + 1) << 16);
+        if (last - first + 1 > p->nc_max) p->nc_max = last - first + 1;
         for (int k = 0; k < 3; ++k) cq[4 * xq + 1 + k] = origin3(xs, first, k);
     }
     int* ri = cq + 4 * (size_t)W4;
     for (int y = 0; y < h; ++y) {
         const int f = rr[y] & 0xffff;
         ri[4 * y + 0] = rr[y];
+        if ((rr[y] >> 16) > p->nr_max) p->nr_max = rr[y] >> 16;
         for (int k = 0; k < 3; ++k) ri[4 * y + 1 + k] = origin3(ys, f, k);
     }
     p->d_xs = p->d_ys = p->d_colrange = p->d_rowrange = nullptr;

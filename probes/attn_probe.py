@@ -4,6 +4,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "multidiffusion-upscaler-for-automatic1111_amd"))
 import mdtile as E
+if os.environ.get("MDTILE_AB_LIB"):      # another build of the library (counter passes of a kernel variant: tools/gpu_r6.sh sqattn)
+    E.LIB_PATH = os.environ["MDTILE_AB_LIB"]
 
 dev = torch.device("cuda:0")
 ZEROS = "--zeros" in sys.argv     # all-zero q / k / v: same instruction stream, no operand toggling (DVFS / power check)

@@ -241,5 +241,5 @@ def test_stream_copy_is_a_copy(plugin, cuda):
         dst = torch.zeros(n + 8, device=cuda)
         E.stream_copy(src, dst[:n])
         assert torch.equal(dst[:n], src) and not dst[n:].any()
-    with pytest.raises(E.MdtileError):
-        E.lib().mdtile_stream_copy(src.data_ptr() + 4, dst.data_ptr(), 64, None)
+    assert E.lib().mdtile_stream_copy(src.data_ptr() + 4, dst.data_ptr(), 64, None) == E.E_ARG        # misaligned source
+    assert E.lib().mdtile_stream_copy(src.data_ptr(), dst.data_ptr(), 60, None) == E.E_ARG            # not a multiple of 16 bytes

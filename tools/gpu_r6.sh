@@ -17,8 +17,18 @@ for w in $WHAT; do
     r6new) (timeout 2400 python -m pytest tests/test_gpu_shard.py tests/test_gpu_vae_stress.py tests/test_gpu_conv_stats.py tests/test_gpu_blend.py -m gpu -q --tb=short -p no:cacheprovider -s --durations=10 2>&1 | grep -v "Tiled VAE\|amdgpu.ids\|Sampling" | tail -70) > $O/pytest_r6new_$TAG.log 2>&1; tail -45 $O/pytest_r6new_$TAG.log;;
     bare8) (timeout 1500 python bench.py --gpus 8 --steps 1 --warmup 0 --no-cpu-baseline --no-profile-pass > $O/bench_bare8_$TAG.json 2> $O/bench_bare8_$TAG.err; echo "rc=$?" >> $O/bench_bare8_$TAG.err); tail -3 $O/bench_bare8_$TAG.err | cut -c1-300; cut -c1-2500 $O/bench_bare8_$TAG.json;;
     sp8) (timeout 1500 python bench.py --gpus 8 --single-process --steps 1 --warmup 1 > $O/bench_sp8_$TAG.json 2> $O/bench_sp8_$TAG.err; echo "rc=$?" >> $O/bench_sp8_$TAG.err); tail -3 $O/bench_sp8_$TAG.err | cut -c1-300; cut -c1-2500 $O/bench_sp8_$TAG.json;;
-    blendab) (timeout 600 python probes/blend_r6_ab.py 2>&1 | grep -v amdgpu.ids) > $O/blend_r6_ab_$TAG.log 2>&1; cat $O/blend_r6_ab_$TAG.log;;
+    blendab) (timeout 900 python probes/blend_r6_ab.py 2>&1 | grep -v amdgpu.ids) > $O/blend_r6_ab_$TAG.log 2>&1
+        if [ -f probes/_ab/libmdtile_r5_blend.so ]; then (MDTILE_AB_LIB=probes/_ab/libmdtile_r5_blend.so timeout 600 python probes/blend_r6_ab.py 2>&1 | grep -v amdgpu.ids) >> $O/blend_r6_ab_$TAG.log 2>&1; fi
+        cat $O/blend_r6_ab_$TAG.log;;
     attnab) (timeout 900 python probes/attn_ab.py probes/_ab/libmdtile_attn_base.so 2>&1 | grep -v amdgpu.ids) > $O/attn_ab_$TAG.log 2>&1; cat $O/attn_ab_$TAG.log;;
+    sqattn) # SQ / GRBM counters of the attention kernel at T = 77 284: the shipping kernel and the rejected round-6 variant (DMA pieces between MFMA pairs)
+        for v in shipping interleaved; do
+          if [ $v = interleaved ]; then export MDTILE_AB_LIB=$R/probes/_ab/libmdtile_attn_interleaved.so; else unset MDTILE_AB_LIB; fi
+          cd /tmp
+          (timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $O/sqa_$TAG -o p -- python $R/probes/attn_probe.py 77284 --quick 2>&1 | tail -3) > $O/sqa_$TAG.log 2>&1
+          (timeout 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/sqb_$TAG -o p -- python $R/probes/attn_probe.py 77284 --quick 2>&1 | tail -3) > $O/sqb_$TAG.log 2>&1
+          cd $R; python tools/pmc_sq.py $O/pmc_sq_attn_${v}_$TAG.json $O/sqa_$TAG $O/sqb_$TAG 2>&1 | grep "k_attn_bf16x3\|kernel" | head -6 | tee $O/pmc_sq_attn_${v}_$TAG.log; rm -rf $O/sqa_$TAG $O/sqb_$TAG
+        done; unset MDTILE_AB_LIB;;
     chk:*) sel=${w#chk:}; (timeout 1800 python -m pytest ${sel//+/ } -m gpu -q --tb=short -p no:cacheprovider -s 2>&1 | grep -v "Tiled VAE\|amdgpu.ids\|Sampling" | tail -50) > $O/pytest_chk_$TAG.log 2>&1; tail -40 $O/pytest_chk_$TAG.log;;
     *) bash $R/tools/gpu_r5.sh $TAG $w;;
   esac
