@@ -408,7 +408,16 @@ namespace mdt {
 
 bool conv1x1_bf16x3_eligible(int cout, int cin) { return cin % 32 == 0 && cout >= 32; }
 // couts per block: 256 (one pass over the input for cout % 256 == 0), 128, or 64 for the small decoders' narrow convs
-static int conv1x1_mt(int cout) { return cout > 128 ? 8 : (cout > 64 ? 4 : 2); }
+// (PROBES twin: MDTILE_C1X1_MT=4 keeps 128-cout blocks -- k_conv1x1_stream<2>, 512-px strips -- for cout % 256 == 0 too; read once: the
+// weight packing depends on it.  Round 6 looked for the roof of k_conv1x1_stream<4> (2.2-3.4 TB/s, 280 TF-eq, 0.39 MFMA-busy, 7.1 VALU per
+// MFMA; profiles/r6h): the block shape does not matter (256 x 256 vs 128 x 512: +-2 %), and neither does the VALU count -- a cooperative
+// once-per-block split of the input into fragment records (1.9 VALU per MFMA, bit-identical, diff in profiles/r6h) ran the same times.  With
+// cin = 512 the kernel needs ~5 TB/s of HBM AND ~10 TB/s of L2 -> LDS weight stream at full matrix rate: it sits at ~45 % of both.)
+static int conv1x1_mt(int cout) {
+    static const int cap = [] { const char* e = probe_env("MDTILE_C1X1_MT"); return e ? atoi(e) : 8; }();
+    const int mt = cout > 128 ? 8 : (cout > 64 ? 4 : 2);
+    return mt > cap ? cap : mt;
+}
 // MDTILE_C1X1_STREAM=0 (probes build only, read per launch): keep the plain kernel on the wide images too
 static bool conv1x1_stream_on() {
     const char* e = probe_env("MDTILE_C1X1_STREAM");

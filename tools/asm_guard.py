@@ -88,8 +88,10 @@ def check_kernel(name: str, ins: list, expect: dict) -> list:
         # walk back over scalar ALU and branches: a wait selected by a (wave-uniform) branch sits in its own basic block in front of
         # the barrier's block, e.g.  s_waitcnt vmcnt(0) / loop header / s_cbranch / s_waitcnt vmcnt(5) / s_barrier
         j, found = k - 1, []
-        # (v_readlane / v_writelane: SGPR spill traffic of the scalar address arithmetic -- register moves, no memory)
-        while j >= 0 and (re.match(r"s_(mov|add|and|or|lshl|lshr|mul|cmp|cselect|sub|ashr|bfe|nop|xor|not|max|min|addc|bitcmp|cbranch|branch|waitcnt)|v_readlane_b32|v_writelane_b32", ins[j])):
+        # (v_readlane / v_writelane: SGPR spill traffic of the scalar address arithmetic -- register moves, no memory; plain integer VALU
+        # address arithmetic that hipcc schedules between the wait and the barrier is harmless as well: it touches no memory and no counter)
+        while j >= 0 and (re.match(r"s_(mov|movk|add|and|andn2|or|lshl|lshr|mul|cmp|cselect|sub|ashr|bfe|nop|xor|not|max|min|addc|bitcmp|cbranch|branch|waitcnt|load_dword)"
+                                   r"|v_readlane_b32|v_writelane_b32|v_(mov|and|or|lshlrev|lshrrev|add|sub|and_or|lshl_add|lshl_or|mad_u32_u24|mul_u32_u24|bfe_u32|add_lshl)_", ins[j])):
             if ins[j].startswith("s_waitcnt"):
                 found.append(ins[j])
             j -= 1

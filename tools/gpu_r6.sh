@@ -29,6 +29,19 @@ for w in $WHAT; do
           (timeout 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/sqb_$TAG -o p -- python $R/probes/attn_probe.py 77284 --quick 2>&1 | tail -3) > $O/sqb_$TAG.log 2>&1
           cd $R; python tools/pmc_sq.py $O/pmc_sq_attn_${v}_$TAG.json $O/sqa_$TAG $O/sqb_$TAG 2>&1 | grep "k_attn_bf16x3\|kernel" | head -6 | tee $O/pmc_sq_attn_${v}_$TAG.log; rm -rf $O/sqa_$TAG $O/sqb_$TAG
         done; unset MDTILE_AB_LIB;;
+    c1x1mt) : > $O/conv1x1_mt_ab_$TAG.log      # 1x1 streaming conv: 256-cout x 256-px blocks (default for cout % 256 == 0) vs 128-cout x 512-px blocks
+        for b in 1 4; do for mt in 8 4; do echo "PROBE_B=$b MDTILE_C1X1_MT=$mt" >> $O/conv1x1_mt_ab_$TAG.log
+          (PROBE_B=$b MDTILE_C1X1_MT=$mt timeout 300 python probes/conv1x1_probe.py 2>&1 | grep "^1x1") >> $O/conv1x1_mt_ab_$TAG.log 2>&1; done; done
+        cat $O/conv1x1_mt_ab_$TAG.log;;
+    sqc1x1) cd /tmp      # SQ / GRBM counters of the 1x1 streaming conv on the decode's shapes (4 stacked tiles)
+        (PROBE_B=4 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $O/sqa_$TAG -o p -- python $R/probes/conv1x1_probe.py 2>&1 | tail -3) > $O/sqa_$TAG.log 2>&1
+        (PROBE_B=4 timeout 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/sqb_$TAG -o p -- python $R/probes/conv1x1_probe.py 2>&1 | tail -3) > $O/sqb_$TAG.log 2>&1
+        cd $R; python tools/pmc_sq.py $O/pmc_sq_c1x1_$TAG.json $O/sqa_$TAG $O/sqb_$TAG 2>&1 | grep "conv1x1\|kernel" | head -8; rm -rf $O/sqa_$TAG $O/sqb_$TAG;;
+    c1x1ab) : > $O/conv1x1_ab_$TAG.log      # 1x1 streaming conv: this tree vs probes/_ab/libmdtile_c1x1_base.so (before the cooperative split), twice each
+        for rep in 1 2; do for b in 1 4; do for lib in base tree; do echo "PROBE_B=$b $lib" >> $O/conv1x1_ab_$TAG.log
+          if [ $lib = base ]; then export MDTILE_AB_LIB=$R/probes/_ab/libmdtile_c1x1_base.so; else unset MDTILE_AB_LIB; fi
+          (PROBE_B=$b timeout 300 python probes/conv1x1_probe.py 2>&1 | grep "^1x1") >> $O/conv1x1_ab_$TAG.log 2>&1; done; done; done; unset MDTILE_AB_LIB
+        cat $O/conv1x1_ab_$TAG.log;;
     chk:*) sel=${w#chk:}; (timeout 1800 python -m pytest ${sel//+/ } -m gpu -q --tb=short -p no:cacheprovider -s 2>&1 | grep -v "Tiled VAE\|amdgpu.ids\|Sampling" | tail -50) > $O/pytest_chk_$TAG.log 2>&1; tail -40 $O/pytest_chk_$TAG.log;;
     *) bash $R/tools/gpu_r5.sh $TAG $w;;
   esac
