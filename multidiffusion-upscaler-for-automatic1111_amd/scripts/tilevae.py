@@ -62,110 +62,13 @@ def get_rcmd_dec_tsize() -> int:
     return 256 if torch.cuda.is_available() else 64
 
 
-# ---------------------------------------------------------------------------------------------------------------------
-# program = upstream's task queue, with the fusions the engine offers already applied
-# ---------------------------------------------------------------------------------------------------------------------
-class Step:
-    __slots__ = ("kind", "conv", "norm", "silu", "attn", "fuse_res", "upsample", "downsample", "channels")
-
-    def __init__(self, kind, conv=None, norm=None, silu=False, attn=None, fuse_res=False, upsample=False, downsample=False, channels=0):
-        self.kind, self.conv, self.norm, self.silu, self.attn = kind, conv, norm, silu, attn
-        self.fuse_res, self.upsample, self.downsample = fuse_res, upsample, downsample
-        self.channels = channels      # norm steps: the GroupNorm's channel count
-
-
-class AttnPack:
-    """q/k/v/proj_out of one AttnBlock, packed for the engine; v is produced token-major for the PV contraction."""
-
-    def __init__(self, attn, pack=None, engine=None):
-        pack = pack or _pack
-        self.engine = engine or mdtile
-        self.q, self.k, self.v, self.proj = (pack(attn.q), pack(attn.k), pack(attn.v), pack(attn.proj_out))
-        self.channels = attn.q.weight.shape[0]
-
-    def __call__(self, h: Tensor, residual: Tensor) -> Tensor:
-        B, C, H, W = h.shape
-        q = self.q(h).view(B, C, H * W)
-        k = self.k(h).view(B, C, H * W)
-        scale = float(int(C) ** (-0.5))
-        if getattr(self.engine, "v_channel_major_ok", lambda c: False)(C):
-            # v like q and k: channel-major through the split-bf16 1x1 kernel; the attention prep reads it in that layout
-            o = self.engine.vae_attn(q, k, self.v(h).view(B, C, H * W), scale, v_channel_major=True)
-        else:
-            o = self.engine.vae_attn(q, k, self.v(h, token_major=True), scale)     # softmax(q^T k / sqrt(C)) v   (attn.py:55-67)
-        return self.proj(o.view(B, C, H, W), residual=residual)        # proj_out + the queue's add_res
-
-
-def _pack(conv) -> mdtile.PackedConv:
-    if conv.stride == (2, 2):
-        # ldm Downsample.conv: 3x3, stride 2, no padding (the module pads right/bottom by one itself) -> PackedConv.down2
-        assert conv.kernel_size == (3, 3) and conv.padding == (0, 0) and conv.dilation == (1, 1) and conv.groups == 1, f"unsupported conv {conv}"
-        return mdtile.PackedConv(conv.weight.detach().float().contiguous(), None if conv.bias is None else conv.bias.detach().float())
-    assert conv.stride == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1, "engine convs are stride-1 (or ldm Downsample) dense"
-    k = conv.kernel_size[0]
-    assert conv.kernel_size == (k, k) and conv.padding == (k // 2, k // 2), f"unsupported conv {conv}"
-    return mdtile.PackedConv(conv.weight.detach().float().contiguous(),
-                             None if conv.bias is None else conv.bias.detach().float())
-
-
-def _norm_params(gn):
-    assert gn.num_groups == 32, "Tiled VAE hard-codes 32 groups (upstream tilevae.py:299)"
-    g = gn.weight.detach().float().contiguous() if getattr(gn, "weight", None) is not None else None
-    b = gn.bias.detach().float().contiguous() if getattr(gn, "bias", None) is not None else None
-    return g, b
-
-
-def _resblock(steps: List[Step], blk, pack):
-    if blk.in_channels != blk.out_channels:
-        shortcut = blk.conv_shortcut if blk.use_conv_shortcut else blk.nin_shortcut
-        steps.append(Step("store_res", conv=pack(shortcut)))
-    else:
-        steps.append(Step("store_res"))
-    steps.append(Step("norm", norm=_norm_params(blk.norm1), silu=True, channels=blk.norm1.num_channels))
-    steps.append(Step("conv", conv=pack(blk.conv1)))
-    steps.append(Step("norm", norm=_norm_params(blk.norm2), silu=True, channels=blk.norm2.num_channels))
-    steps.append(Step("conv", conv=pack(blk.conv2), fuse_res=True))       # conv2 + add_res in one epilogue
-
-
-def build_task_queue(net, is_decoder: bool = True, pack=None, engine=None) -> List[Step]:
-    """Linearise an ldm Decoder exactly in upstream's order (:139-195): conv_in, mid(res, attn, res), levels top-down
-    with num_res_blocks+1 resblocks (+ upsample except on level 0), norm_out, silu, conv_out.  30 norms for SD/SDXL.
-    `pack` turns an nn.Conv2d into the callable a step carries and `engine` is the module the attention step calls
-    (defaults: mdtile.PackedConv / mdtile; the CPU tests of the host logic inject torch doubles, tests/torch_engine.py)."""
-    pack = pack or _pack
-    steps = [Step("conv", conv=pack(net.conv_in))]
-
-    def _mid():
-        _resblock(steps, net.mid.block_1, pack)
-        steps.extend([Step("store_res"), Step("norm", norm=_norm_params(net.mid.attn_1.norm), channels=net.mid.attn_1.norm.num_channels),
-                      Step("attn", attn=AttnPack(net.mid.attn_1, pack, engine))])
-        _resblock(steps, net.mid.block_2, pack)
-
-    if is_decoder:
-        _mid()
-        for lvl in reversed(range(net.num_resolutions)):
-            for i in range(net.num_res_blocks + 1):
-                _resblock(steps, net.up[lvl].block[i], pack)
-            if lvl != 0:
-                steps.append(Step("conv", conv=pack(net.up[lvl].upsample.conv), upsample=True))  # nearest-2x fused
-    else:
-        # encoder (upstream :155-171): levels bottom-up with num_res_blocks resblocks (+ downsample except on the last), then mid
-        for lvl in range(net.num_resolutions):
-            for i in range(net.num_res_blocks):
-                _resblock(steps, net.down[lvl].block[i], pack)
-            if lvl != net.num_resolutions - 1:
-                steps.append(Step("conv", conv=pack(net.down[lvl].downsample.conv), downsample=True))
-        _mid()
-    if not is_decoder or not net.give_pre_end:
-        steps.append(Step("norm", norm=_norm_params(net.norm_out), silu=True, channels=net.norm_out.num_channels))
-        steps.append(Step("conv", conv=pack(net.conv_out)))
-        if is_decoder and net.tanh_out:
-            steps.append(Step("tanh"))
-    return steps
+# the program (task queue with the engine's fusions), live-window arithmetic, crop_valid_region, GroupNormParam, TileState
+from tile_utils.vae_program import (AttnPack, GroupNormParam, Step, TileState, _norm_params, _pack, _resblock,      # noqa: E402,F401
+                                    build_task_queue, crop_valid_region, live_windows)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# GroupNorm statistics (upstream :207-245, :289-361)
+# GroupNorm statistics (upstream :207-245; the slow-mode collector GroupNormParam, :289-361, lives in tile_utils/vae_program.py)
 # ---------------------------------------------------------------------------------------------------------------------
 def get_var_mean(input: Tensor, num_groups: int, eps: float = 1e-6) -> Tuple[Tensor, Tensor]:
     return mdtile.gn_stats(input, num_groups)
@@ -175,94 +78,7 @@ def custom_group_norm(input, num_groups, mean, var, weight=None, bias=None, eps=
     return mdtile.gn_apply(input, mean, var, weight, bias, num_groups, eps, silu)
 
 
-def crop_valid_region(x, input_bbox, target_bbox, is_decoder):
-    padded = [i * 8 if is_decoder else i // 8 for i in input_bbox]
-    m = [target_bbox[i] - padded[i] for i in range(4)]
-    return x[:, :, m[2]:x.size(2) + m[3], m[0]:x.size(3) + m[1]]
-
-
-def live_windows(steps: List["Step"], tile_hw: Tuple[int, int], valid: Tuple[int, int, int, int]):
-    """Live-window narrowing of ONE decoder tile whose GroupNorm statistics are all frozen (fast mode).
-
-    Upstream decodes the whole padded tile and crop_valid_region (:248-259, applied at :630-632) keeps `valid` (y0, x0, y1, x1 in latent
-    px relative to the tile; the padding -- 11 latent px for the decoder, :371 -- is thrown away).  With frozen statistics every layer
-    behind the attention is local (3x3 convs, 1x1 convs, pointwise norm / SiLU, nearest 2x), so an output pixel further than the number
-    of 3x3 convs still to come from the valid region cannot reach it and need not be computed.  The plane is narrowed where it is
-    cheapest, at the upsample convs: walking the program backwards, `need` counts the 3x3 convs behind a point in pixels of that
-    level; at the upsample conv that opens a level of `scale` px per latent px the plane becomes `valid` grown by
-    ceil(need / scale) latent px (whole latent px: the tile's own crop and store stay in latent units), clamped to the tile, and
-    the level below has to provide ceil((need + 1) / 2) px: an output pixel d px outside the valid region reads the nearest-2x
-    image d - 1 .. d + 1 px outside, i.e. input pixels up to ceil((d + 1) / 2) px outside (the window's own outermost inputs come
-    from the un-narrowed input image, so they are its true neighbours).  A narrowed plane is a zero-padded image of its own: its
-    errors creep inwards one pixel per conv and stop at the valid region.  The walk ends at the attention (it needs every token).
-    SD decoder (3 resblocks per level, conv_out): need = 7, 10, 12 px -> grow = 1, 3, 6 latent px for the 8x, 4x, 2x levels; the 1x
-    level would need 13 of its 11 px of padding and stays whole.  (tests/test_vae_host_logic.py: exact and tight in float64.)
-
-    Returns ({index of the upsample step: (y0, x0, h, w) window of ITS input plane, in input px}, final rect in latent px relative to
-    the tile (y0, x0, y1, x1)) -- ({}, whole tile) when nothing can be shed."""
-    th, tw = tile_hw
-    whole = (0, 0, th, tw)
-    ups = [i for i, s in enumerate(steps) if s.kind == "conv" and s.upsample]
-    if not ups or any(s.kind == "conv" and s.downsample for s in steps):
-        return {}, whole
-    scale, need, grow = 1 << len(ups), 0, {}
-    for i in range(len(steps) - 1, -1, -1):
-        s = steps[i]
-        if s.kind == "attn":
-            break
-        if s.kind != "conv":
-            continue                       # frozen norm, SiLU, residual bookkeeping (+ 1x1 nin_shortcut), tanh: pointwise
-        ks = int(getattr(s.conv, "ksize", 3))
-        if s.upsample:
-            grow[i] = -(-need // scale)    # whole latent px
-            scale //= 2
-            need = (need + ks // 2 + 1) // 2
-        else:
-            need += ks // 2
-    vy0, vx0, vy1, vx1 = valid
-    windows, cur, in_scale = {}, whole, 1
-    for i in ups:
-        if i in grow:
-            m = grow[i]
-            rect = (max(cur[0], vy0 - m), max(cur[1], vx0 - m), min(cur[2], vy1 + m), min(cur[3], vx1 + m))
-            if rect != cur:
-                windows[i] = ((rect[0] - cur[0]) * in_scale, (rect[1] - cur[1]) * in_scale,
-                              (rect[2] - rect[0]) * in_scale, (rect[3] - rect[1]) * in_scale)
-                cur = rect
-        in_scale *= 2
-    return windows, cur
-
-
-class GroupNormParam:
-    """Slow-mode collector: per-tile (var, mean) rows pooled by pixel count (upstream :289-335)."""
-
-    def __init__(self, engine=None):
-        self.engine = engine or mdtile
-        self.var_list, self.mean_list, self.pixel_list = [], [], []
-
-    def add_tile(self, tile: Tensor, stats=None):
-        """stats: (var, mean) of `tile` when its producer has already left them (TileState.stats); else one pass over the tile."""
-        var, mean = stats if stats is not None else self.engine.gn_stats(tile, 32)
-        self.var_list.append(var)
-        self.mean_list.append(mean)
-        self.pixel_list.append(tile.shape[2] * tile.shape[3])
-
-    def summary(self) -> Optional[Tuple[Tensor, Tensor]]:
-        if not self.var_list:
-            return None
-        return self.engine.gn_pool(torch.vstack(self.mean_list), torch.vstack(self.var_list), self.pixel_list)
-
-
 # ---------------------------------------------------------------------------------------------------------------------
-class TileState:
-    __slots__ = ("x", "res", "pc", "pre", "stats")
-
-    def __init__(self, x):
-        self.x, self.res, self.pc = x, [], 0
-        self.pre = None   # pending fused pre-activation: gn_coeffs of the norm just resolved, consumed by the next conv
-        self.stats = None  # slow mode: (var, mean) of x, left by the conv that produced it (None: nobody has them yet)
-
-
 class VAEHook:
 
     def __init__(self, net, tile_size, is_decoder: bool, fast_decoder: bool, fast_encoder: bool, color_fix: bool,
@@ -687,6 +503,173 @@ class VAEHook:
         print(f"[Tiled VAE]: Done in {time() - t0:.3f}s on {len(devs)} devices")
         return out.to(dtype)
 
+    # ---- the tile sweep (upstream vae_tile_forward, :507-656) ------------------------------------------------------------------------
+    # vae_tile_forward is the driver: split, estimator, deal the tiles, run ONE of three sweeps, assemble.
+    #   _sweep_frozen      every norm frozen (fast mode): each tile runs start to finish on its own -- stacked by shape on the record path
+    #   _sweep_lockstep    slow mode / color_fix: all tiles advance from norm to norm, statistics pooled at each one
+    #   _multi_device_sweep  fast mode on several devices of one process (above)
+    class _Run:
+        """State of one vae_tile_forward call shared by the sweeps: this rank's tiles, the result canvas, the NaN flags, the live windows."""
+
+        def __init__(self, hook, z, in_bboxes, out_bboxes, mine):
+            self.hook, self.z, self.in_bboxes, self.out_bboxes, self.mine = hook, z, in_bboxes, out_bboxes, list(mine)
+            E = hook.engine
+            sel = set(mine)
+            self.tiles = {i: TileState(E.gather_rect(z, b[0], b[2], b[1] - b[0], b[3] - b[2])) for i, b in enumerate(in_bboxes) if i in sel}
+            self.result = None
+            self.nan_flags = []
+            self.live = {}          # tile -> (windows of its upsample convs, the input bbox of what is left of it): live_windows
+            self.interrupted = False
+
+        def finish(self, i: int):
+            """crop_valid_region + `result[...] = tile` of one finished tile (upstream :630-632); the canvas appears with the first one."""
+            hook, E, z = self.hook, self.hook.engine, self.z
+            x = self.tiles[i].x
+            if self.result is None:
+                N, _, height, width = z.shape
+                oh, ow = (height * 8, width * 8) if hook.is_decoder else (height // 8, width // 8)
+                self.result = torch.zeros((N, x.shape[1], oh, ow), device=z.device, dtype=torch.float32)
+            self.nan_flags.append(torch.isnan(x).all())       # upstream tests every tile (:626); here ONE host read per decode
+            E.crop_store(x, self.live[i][1] if i in self.live else self.in_bboxes[i], self.out_bboxes[i], self.result, hook.is_decoder)
+            self.tiles[i] = None
+
+    def _sweep_frozen(self, run: "VAEHook._Run", steps: List[Step], frozen) -> None:
+        """Every norm is already resolved: each tile runs start to finish on its own (upstream: one sweep, :578-642)."""
+        E, z, tiles, mine = self.engine, run.z, run.tiles, run.mine
+        N, dev = z.shape[0], z.device
+        use_rec = REC_PATH and hasattr(E, "rec_from_f32")
+        if use_rec:
+            norm_ord = {i: k for k, i in enumerate(i for i, s in enumerate(steps) if s.kind == "norm")}
+            coefs = [E.gn_coeffs(mean, var, steps[i].norm[0], steps[i].norm[1], steps[i].channels, 32, 1e-6)
+                     for i, (var, mean) in zip(norm_ord, frozen)]
+            for i in mine:
+                run.live[i] = self._live_plan(steps, run.in_bboxes[i], run.out_bboxes[i])
+        if use_rec and TILE_BATCH > 1:
+            # Tiles of one shape go through the sweep TOGETHER (stacked along the batch axis, TILE_BATCH at a time).  Upstream
+            # walks them one by one (:578-642); with frozen statistics they are independent, so the result is the same -- but
+            # a conv launch over one tile fills the 256 CUs in ceil(items / 256) rounds and the last round is mostly empty
+            # (256 -> 256 at 1112^2: 4 900 items = 19.1 rounds, 4 % idle; 512 -> 512 at 278^2: 2.5 rounds, 16 % idle).
+            # 288 GB of HBM hold several tiles' activations at once (4 tiles of 278^2: ~53 GB).
+            # Tiles stack by (shape, window SIZES of their narrowed upsample convs): each tile keeps its own window ORIGIN
+            # (mdtile_upconv2d_rec_window takes one per image), so e.g. the interior tiles of every row share their launches.  A chunk
+            # runs start to finish in ONE pass.
+            rep_cache: Dict[int, tuple] = {1: (frozen, coefs)}
+
+            def rep(T):                          # frozen statistics / coefficient rows of a T-deep stack (built once per depth)
+                if T not in rep_cache:
+                    rep_cache[T] = ([(v.repeat(T), m.repeat(T)) for v, m in frozen], [c.repeat(T, 1, 1) for c in coefs])
+                return rep_cache[T]
+
+            def regather(chunk):                 # inputs that were folded into a stacked copy: cut them out of z again
+                for i in chunk:                  # (tiles of the chunk that already FINISHED -- an OOM inside finish() -- are None: left alone)
+                    if tiles[i] is not None:
+                        b = run.in_bboxes[i]
+                        tiles[i].x = E.gather_rect(z, b[0], b[2], b[1] - b[0], b[3] - b[2])
+
+            def run_stack(chunk):
+                T = len(chunk)
+                xb = tiles[chunk[0]].x if T == 1 else torch.cat([tiles[i].x for i in chunk], dim=0)     # (4-channel latent tiles: KBs)
+                fz, cf = rep(T)
+                if T > 1:
+                    for i in chunk:
+                        tiles[i].x = None          # the stacked copy is the live one
+                w0 = run.live[chunk[0]][0]
+                wins = {k: ([run.live[i][0][k][0] for i in chunk for _ in range(N)], [run.live[i][0][k][1] for i in chunk for _ in range(N)], w[2], w[3])
+                        for k, w in w0.items()} if w0 else None
+                yb = self._run_tile_rec(steps, xb, fz, cf, norm_ord, wins)
+                for t, i in enumerate(chunk):
+                    tiles[i].x = yb[t * N:(t + 1) * N]
+                    run.finish(i)
+
+            groups: Dict[tuple, List[int]] = {}
+            for i in mine:
+                groups.setdefault(tuple(tiles[i].x.shape[2:]) + tuple((k, w[2], w[3]) for k, w in sorted(run.live[i][0].items())), []).append(i)
+            for key in sorted(groups, key=lambda kk: -len(groups[kk])):
+                ids = groups[key]
+                tb = self._tile_batch_that_fits(N, key[:2], dev)
+                if len(key) > 2 and tb * N > 8:       # the group carries narrowed windows (key = shape + window entries):
+                    tb = max(1, 8 // N)               # mdtile_upconv2d_rec_window keeps 8 window origins per launch
+                c0 = 0
+                while c0 < len(ids):
+                    if state.interrupted:
+                        run.interrupted = True
+                        return
+                    chunk = [i for i in ids[c0:c0 + tb] if tiles[i] is not None]      # (after an OOM retry: not the tiles that finished)
+                    if not chunk:
+                        c0 += tb
+                        continue
+                    try:
+                        run_stack(chunk)
+                    except torch.cuda.OutOfMemoryError:
+                        if len(chunk) == 1:
+                            raise
+                        print(f"[Tiled VAE]: {len(chunk)} stacked tiles do not fit in VRAM, continuing one tile per sweep")
+                        torch.cuda.empty_cache()
+                        regather(chunk)
+                        tb = 1
+                        continue
+                    c0 += tb
+            return
+        for i in mine:
+            if state.interrupted:
+                run.interrupted = True
+                return
+            st, k = tiles[i], 0
+            if use_rec:
+                st.x = self._run_tile_rec(steps, st.x, frozen, coefs, norm_ord, run.live[i][0])
+                run.finish(i)
+                continue
+            while True:
+                self._run_until_norm(steps, st)
+                if st.pc >= len(steps):
+                    break
+                self._apply_norm(steps, st, *frozen[k])
+                k += 1
+            run.finish(i)
+
+    def _sweep_lockstep(self, run: "VAEHook._Run", steps: List[Step], frozen) -> None:
+        """Slow mode: all tiles advance in lockstep from norm to norm, the statistics pooled over the tiles (and ranks) at each one
+        (upstream :289-361, :578-642 zig-zag); semi-fast (color_fix): the first len(frozen) norms use the frozen statistics instead."""
+        tiles, mine = run.tiles, run.mine
+        world = self.shard[1]
+        forward, k_norm = True, 0
+        while True:
+            use_frozen = frozen is not None and k_norm < len(frozen)
+            gp = GroupNormParam(self.engine)
+            for i in (() if run.interrupted else mine if forward else reversed(mine)):
+                if state.interrupted:
+                    run.interrupted = True
+                    break
+                self._run_until_norm(steps, tiles[i], want_stats=not use_frozen)
+                if tiles[i].pc < len(steps) and not use_frozen:
+                    gp.add_tile(tiles[i].x, tiles[i].stats)
+            if run.interrupted and world == 1:
+                return
+            # several ranks: an interrupted rank runs no more tiles but keeps walking the norms to the next POOLED barrier, where the
+            # `head` exchange tells every rank (see _pooled_across_ranks) -- all of them leave this loop at the same barrier
+            if use_frozen:
+                # a frozen norm is no barrier upstream (the tile runs straight through it): no pooling, no collective,
+                # no change of the zig-zag direction.  A later pooled norm always exists in this branch.
+                for i in (() if run.interrupted else mine):
+                    self._apply_norm(steps, tiles[i], *frozen[k_norm])
+                k_norm += 1
+                continue
+            if world == 1:
+                pooled = gp.summary()
+            else:
+                pooled, any_interrupted = self._pooled_across_ranks(gp, steps, run.z.device, run.interrupted)
+                if any_interrupted:
+                    run.interrupted = True
+                    return
+            k_norm += 1
+            if pooled is None:
+                for i in mine:
+                    run.finish(i)
+                return
+            for i in mine:
+                self._apply_norm(steps, tiles[i], *pooled)
+            forward = not forward
+
     @torch.no_grad()
     def vae_tile_forward(self, z: Tensor) -> Tensor:
         t0 = time()
@@ -701,184 +684,41 @@ class VAEHook:
         print(f"[Tiled VAE]: input_size: {z.shape}, tile_size: {self.tile_size}, padding: {self.pad}")
         in_bboxes, out_bboxes = self.split_tiles(height, width)
         steps = self.program()
+        rank, world = self.shard
 
         frozen = None
         if self.fast_mode:
             zs = E.vae_fast_input(z, self.tile_size)
             print(f"[Tiled VAE]: Fast mode enabled, estimating group norm parameters on {zs.shape[3]} x {zs.shape[2]} image")
-            rank, world = self.shard
             if world > 1 and SP_ESTIMATOR and self.is_decoder and zs.shape[2] >= 2 * world:
                 # the estimator is one untiled pass: split it by rows across the ranks instead of repeating it on each
                 from mdtile import seqpar
                 frozen = seqpar.estimate_group_norm_sp(steps, zs, seqpar.BandComm(rank, world), self._sp_ops or seqpar.EngineOps(), FUSE_PRE_GN)
             else:
                 frozen = self.estimate_group_norm(zs, steps)
+        all_frozen = frozen is not None and len(frozen) == sum(1 for s in steps if s.kind == "norm")
+        if all_frozen and self.devices and len(self.devices) > 1 and dev.type == "cuda":
+            return self._multi_device_sweep(z, steps, frozen, in_bboxes, out_bboxes, dtype, t0)
 
-        rank, world = self.shard
         owner = [0] * len(in_bboxes)
         if world > 1:
             from mdtile import sharding as _sh
             owner = _sh.deal_tiles(in_bboxes, world)      # by tile area (mdtile/sharding.py: deal_tiles), the same list on every rank
         mine = [i for i in range(len(in_bboxes)) if owner[i] == rank] if world > 1 else list(range(len(in_bboxes)))
-        tiles = {i: TileState(E.gather_rect(z, b[0], b[2], b[1] - b[0], b[3] - b[2])) for i, b in enumerate(in_bboxes) if i in set(mine)}
-        result = None
-        interrupted = False
-
-        nan_flags = []
-        live: Dict[int, tuple] = {}      # tile -> (windows of its upsample convs, the input bbox of what is left of it): live_windows
-
-        def finish(i: int):
-            nonlocal result
-            x = tiles[i].x
-            if result is None:
-                oh, ow = (height * 8, width * 8) if self.is_decoder else (height // 8, width // 8)
-                result = torch.zeros((N, x.shape[1], oh, ow), device=dev, dtype=torch.float32)
-            nan_flags.append(torch.isnan(x).all())       # upstream tests every tile (:626); here ONE host read per decode, below
-            E.crop_store(x, live[i][1] if i in live else in_bboxes[i], out_bboxes[i], result, self.is_decoder)
-            tiles[i] = None
-
-        n_norm_total = sum(1 for s in steps if s.kind == "norm")
-        if frozen is not None and len(frozen) == n_norm_total:
-            # every norm is already resolved: each tile runs start to finish on its own (upstream: one sweep)
-            if self.devices and len(self.devices) > 1 and dev.type == "cuda":
-                return self._multi_device_sweep(z, steps, frozen, in_bboxes, out_bboxes, dtype, t0)
-            use_rec = REC_PATH and hasattr(E, "rec_from_f32")
-            if use_rec:
-                norm_ord = {i: k for k, i in enumerate(i for i, s in enumerate(steps) if s.kind == "norm")}
-                coefs = [E.gn_coeffs(mean, var, steps[i].norm[0], steps[i].norm[1], steps[i].channels, 32, 1e-6)
-                         for i, (var, mean) in zip(norm_ord, frozen)]
-                for i in mine:
-                    live[i] = self._live_plan(steps, in_bboxes[i], out_bboxes[i])
-            if use_rec and TILE_BATCH > 1:
-                # Tiles of one shape go through the sweep TOGETHER (stacked along the batch axis, TILE_BATCH at a time).  Upstream
-                # walks them one by one (:578-642); with frozen statistics they are independent, so the result is the same -- but
-                # a conv launch over one tile fills the 256 CUs in ceil(items / 256) rounds and the last round is mostly empty
-                # (256 -> 256 at 1112^2: 4 900 items = 19.1 rounds, 4 % idle; 512 -> 512 at 278^2: 2.5 rounds, 16 % idle).
-                # 288 GB of HBM hold several tiles' activations at once (4 tiles of 278^2: ~53 GB).
-                # Tiles stack by (shape, window SIZES of their narrowed upsample convs): each tile keeps its own window ORIGIN
-                # (mdtile_upconv2d_rec_window takes one per image), so e.g. the interior tiles of every row share their launches.  A chunk
-                # runs start to finish in ONE pass -- round 3 cut the sweep in front of the first narrowed conv to stack the 1x level by
-                # shape alone and re-stacked the halves with torch.cat: six 0.57 GB copies per 8K decode, more than the fuller launches saved.
-                rep_cache: Dict[int, tuple] = {1: (frozen, coefs)}
-
-                def rep(T):                          # frozen statistics / coefficient rows of a T-deep stack (built once per depth)
-                    if T not in rep_cache:
-                        rep_cache[T] = ([(v.repeat(T), m.repeat(T)) for v, m in frozen], [c.repeat(T, 1, 1) for c in coefs])
-                    return rep_cache[T]
-
-                def regather(chunk):                 # inputs that were folded into a stacked copy: cut them out of z again
-                    for i in chunk:                  # (tiles of the chunk that already FINISHED -- an OOM inside finish() -- are None: left alone)
-                        if tiles[i] is not None:
-                            b = in_bboxes[i]
-                            tiles[i].x = E.gather_rect(z, b[0], b[2], b[1] - b[0], b[3] - b[2])
-
-                def run_stack(chunk):
-                    T = len(chunk)
-                    xb = tiles[chunk[0]].x if T == 1 else torch.cat([tiles[i].x for i in chunk], dim=0)     # (4-channel latent tiles: KBs)
-                    fz, cf = rep(T)
-                    if T > 1:
-                        for i in chunk:
-                            tiles[i].x = None          # the stacked copy is the live one
-                    w0 = live[chunk[0]][0]
-                    wins = {k: ([live[i][0][k][0] for i in chunk for _ in range(N)], [live[i][0][k][1] for i in chunk for _ in range(N)], w[2], w[3])
-                            for k, w in w0.items()} if w0 else None
-                    yb = self._run_tile_rec(steps, xb, fz, cf, norm_ord, wins)
-                    for t, i in enumerate(chunk):
-                        tiles[i].x = yb[t * N:(t + 1) * N]
-                        finish(i)
-
-                def sweep(groups, run_chunk, restore):
-                    nonlocal interrupted
-                    for key in sorted(groups, key=lambda kk: -len(groups[kk])):
-                        ids = groups[key]
-                        tb = self._tile_batch_that_fits(N, key[:2], dev)
-                        if len(key) > 2 and tb * N > 8:       # the group carries narrowed windows (key = shape + window entries):
-                            tb = max(1, 8 // N)               # mdtile_upconv2d_rec_window keeps 8 window origins per launch
-                        c0 = 0
-                        while c0 < len(ids):
-                            if state.interrupted:
-                                interrupted = True
-                                return
-                            chunk = [i for i in ids[c0:c0 + tb] if tiles[i] is not None]      # (after an OOM retry: not the tiles that finished)
-                            if not chunk:
-                                c0 += tb
-                                continue
-                            try:
-                                run_chunk(chunk)
-                            except torch.cuda.OutOfMemoryError:
-                                if len(chunk) == 1:
-                                    raise
-                                print(f"[Tiled VAE]: {len(chunk)} stacked tiles do not fit in VRAM, continuing one tile per sweep")
-                                torch.cuda.empty_cache()
-                                restore(chunk)
-                                tb = 1
-                                continue
-                            c0 += tb
-
-                groups: Dict[tuple, List[int]] = {}
-                for i in mine:
-                    groups.setdefault(tuple(tiles[i].x.shape[2:]) + tuple((k, w[2], w[3]) for k, w in sorted(live[i][0].items())), []).append(i)
-                sweep(groups, run_stack, regather)
-                mine = []        # all done (or interrupted)
-            for i in mine:
-                if state.interrupted:
-                    interrupted = True
-                    break
-                st, k = tiles[i], 0
-                if use_rec:
-                    st.x = self._run_tile_rec(steps, st.x, frozen, coefs, norm_ord, live[i][0])
-                    finish(i)
-                    continue
-                while True:
-                    self._run_until_norm(steps, st)
-                    if st.pc >= len(steps):
-                        break
-                    self._apply_norm(steps, st, *frozen[k])
-                    k += 1
-                finish(i)
+        run = VAEHook._Run(self, z, in_bboxes, out_bboxes, mine)
+        if all_frozen:
+            self._sweep_frozen(run, steps, frozen)
         else:
-            # slow mode: all tiles advance in lockstep from norm to norm; statistics pooled over tiles at each one
-            # (semi-fast: the first len(frozen) norms use the frozen statistics instead of the pool)
-            forward = True
-            k_norm = 0
-            while True:
-                use_frozen = frozen is not None and k_norm < len(frozen)
-                gp = GroupNormParam(E)
-                for i in (() if interrupted else mine if forward else reversed(mine)):
-                    if state.interrupted:
-                        interrupted = True
-                        break
-                    self._run_until_norm(steps, tiles[i], want_stats=not use_frozen)
-                    if tiles[i].pc < len(steps) and not use_frozen:
-                        gp.add_tile(tiles[i].x, tiles[i].stats)
-                if interrupted and world == 1:
-                    break
-                # several ranks: an interrupted rank runs no more tiles but keeps walking the norms to the next POOLED barrier, where the
-                # `head` exchange tells every rank (see _pooled_across_ranks) -- all of them leave this loop at the same barrier
-                if use_frozen:
-                    # a frozen norm is no barrier upstream (the tile runs straight through it): no pooling, no collective,
-                    # no change of the zig-zag direction.  A later pooled norm always exists in this branch.
-                    for i in (() if interrupted else mine):
-                        self._apply_norm(steps, tiles[i], *frozen[k_norm])
-                    k_norm += 1
-                    continue
-                if world == 1:
-                    pooled = gp.summary()
-                else:
-                    pooled, any_interrupted = self._pooled_across_ranks(gp, steps, z.device, interrupted)
-                    if any_interrupted:
-                        interrupted = True
-                        break
-                k_norm += 1
-                if pooled is None:
-                    for i in mine:
-                        finish(i)
-                    break
-                for i in mine:
-                    self._apply_norm(steps, tiles[i], *pooled)
-                forward = not forward
+            self._sweep_lockstep(run, steps, frozen)
+        return self._assemble(run, owner, dtype, t0)
 
-        nan_seen = bool(nan_flags) and bool(torch.stack(nan_flags).any().item())
+    def _assemble(self, run: "VAEHook._Run", owner, dtype, t0) -> Tensor:
+        """NaN test of the image (upstream :633-634), the gather of the other ranks' rectangles, upstream's interrupt results (:644-650)."""
+        net, z, result, interrupted = self.net, run.z, run.result, run.interrupted
+        dev = z.device
+        N, _, height, width = z.shape
+        rank, world = self.shard
+        nan_seen = bool(run.nan_flags) and bool(torch.stack(run.nan_flags).any().item())
         if world > 1 and self.gather_to is not None:
             # The gather below is a grouped exchange EVERY rank must enter (or none): a rank that was interrupted, or whose NaN check
             # raises, would leave the others -- and the root's receives -- waiting for ever.  So the ranks first agree on both flags (one
@@ -897,7 +737,7 @@ class VAEHook:
                 result = torch.zeros((N, 3 if self.is_decoder else 2 * int(getattr(net, "z_channels", 4)),
                                       *((height * 8, width * 8) if self.is_decoder else (height // 8, width // 8))), device=dev, dtype=torch.float32)
             if result is not None:
-                sharding.gather_tiles_to_root(result, out_bboxes, lambda i: owner[i], rank, self.gather_to)
+                sharding.gather_tiles_to_root(result, run.out_bboxes, lambda i: owner[i], rank, self.gather_to)
         self.last_seconds = time() - t0
         if interrupted and result is not None:
             return result.to(dtype)          # upstream hands back what is finished (:644-647)
