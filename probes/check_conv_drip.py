@@ -1,4 +1,4 @@
-"""Bit-identity check of the dripped-epilogue record conv (probes/probes/csrc/vae_conv_recd.hip) against the shipping one-block kernel.  The
+"""Bit-identity check of the dripped-epilogue record conv (probes/csrc/vae_conv_recd.hip) against the shipping one-block kernel.  The
 kernel was built, measured and rejected in round 5 (docs/history/r5.md); since round 6 it lives in the PROBES twin of the library only
 (python -m mdtile.build --probes), so this check is a probe, not part of tests/:
         python -m pytest probes/check_conv_drip.py -q          (on the GPU box)"""

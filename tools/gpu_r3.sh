@@ -12,12 +12,12 @@ for w in $WHAT; do
     new) (timeout 900 python -m pytest tests/test_gpu_shard.py tests/test_md_entry_path.py tests/test_gpu_vae_large.py -m gpu -q --tb=short -p no:cacheprovider -s --durations=8 2>&1 | grep -v "Tiled VAE\|amdgpu.ids\|Sampling" | tail -60) > $O/pytest_new_$TAG.log 2>&1; tail -30 $O/pytest_new_$TAG.log;;
     smoke) (timeout 300 python __graft_entry__.py smoke 2>&1 | tail -2) > $O/smoke_$TAG.log 2>&1; cat $O/smoke_$TAG.log;;
     bench) (timeout 1200 python bench.py --steps 2 --warmup 1 2>&1 | tail -1) > $O/bench_$TAG.json 2>&1; cut -c1-6000 $O/bench_$TAG.json;;
-    benchq) (timeout 600 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-f32-pass --no-oracle-pass --no-whole-tile-pass --no-stress-pass 2>&1 | tail -1) > $O/benchq_$TAG.json 2>&1; cut -c1-4000 $O/benchq_$TAG.json;;
-    prof) cd /tmp; (timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-f32-pass --no-oracle-pass --no-whole-tile-pass --no-stress-pass 2>&1 | tail -3) > $O/rocprof_$TAG.log 2>&1; cd $R
+    benchq) (timeout 600 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-f32-pass --no-oracle-pass --no-whole-tile-pass --no-stress-pass --no-companions 2>&1 | tail -1) > $O/benchq_$TAG.json 2>&1; cut -c1-4000 $O/benchq_$TAG.json;;
+    prof) cd /tmp; (timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-f32-pass --no-oracle-pass --no-whole-tile-pass --no-stress-pass --no-companions 2>&1 | tail -3) > $O/rocprof_$TAG.log 2>&1; cd $R
           find $O/prof_$TAG -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_$TAG.csv \; ; head -14 $O/kernel_stats_$TAG.csv | cut -c1-200; rm -rf $O/prof_$TAG;;
     pmc) cd /tmp
-         (timeout 600 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_fetch_$TAG -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile-pass --no-f32-pass --no-oracle-pass --no-whole-tile-pass --no-stress-pass 2>&1 | tail -3) > $O/pmc_fetch_$TAG.log 2>&1
-         (timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$TAG -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile-pass --no-f32-pass --no-oracle-pass --no-whole-tile-pass --no-stress-pass 2>&1 | tail -3) > $O/pmc_write_$TAG.log 2>&1
+         (timeout 600 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_fetch_$TAG -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile-pass --no-f32-pass --no-oracle-pass --no-whole-tile-pass --no-stress-pass --no-companions 2>&1 | tail -3) > $O/pmc_fetch_$TAG.log 2>&1
+         (timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$TAG -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile-pass --no-f32-pass --no-oracle-pass --no-whole-tile-pass --no-stress-pass --no-companions 2>&1 | tail -3) > $O/pmc_write_$TAG.log 2>&1
          cd $R; (python tools/pmc_summary.py $O/pmc_fetch_$TAG $O/pmc_write_$TAG $O/pmc_hbm_summary_$TAG.json) > $O/pmc_summary_$TAG.log 2>&1; cat $O/pmc_summary_$TAG.log; tail -2 $O/pmc_fetch_$TAG.log; rm -rf $O/pmc_fetch_$TAG $O/pmc_write_$TAG;;
     rccl) cd /tmp   # RCCL kernels of the 1-rank communicator tests, by name
           (timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rccl_$TAG -o rccl -- python -m pytest $R/tests/test_gpu_shard.py -m gpu -q -p no:cacheprovider -k "rccl_one_rank" 2>&1 | tail -5) > $O/rccl_$TAG.log 2>&1; cd $R

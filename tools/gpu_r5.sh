@@ -26,11 +26,11 @@ for w in $WHAT; do
         cat $O/conv_drip_ab_$TAG.log;;
     encode) (timeout 900 python bench.py --encode --steps 2 --warmup 1 2>&1 | tail -1) > $O/bench_encode_$TAG.json 2>&1; cut -c1-3000 $O/bench_encode_$TAG.json;;
     stress) (timeout 900 python -m pytest tests/test_gpu_vae_stress.py -m gpu -q -s -p no:cacheprovider 2>&1 | grep "stress\|attention at\|passed\|failed") > $O/pytest_stress_$TAG.log 2>&1; cat $O/pytest_stress_$TAG.log;;
-    sqbench) cd /tmp; BF="--steps 1 --warmup 0 --no-cpu-baseline --no-profile-pass --no-f32-pass --no-oracle-pass --no-whole-tile-pass --no-stress-pass"
+    sqbench) cd /tmp; BF="--steps 1 --warmup 0 --no-cpu-baseline --no-profile-pass --no-f32-pass --no-oracle-pass --no-whole-tile-pass --no-stress-pass --no-companions"
         (timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $O/sqm_a_$TAG -o p -- python $R/bench.py $BF 2>&1 | tail -2) > $O/sqm_a_$TAG.log 2>&1
         (timeout 600 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/sqm_b_$TAG -o p -- python $R/bench.py $BF 2>&1 | tail -2) > $O/sqm_b_$TAG.log 2>&1
         cd $R; python tools/pmc_sq.py $O/pmc_sq_summary_$TAG.json $O/sqm_a_$TAG $O/sqm_b_$TAG 2>&1 | grep "k_conv3x3_rec\|k_attn_bf16x3\|k_upconv_rec\|kernel" | head -20 | tee $O/pmc_sq_$TAG.log; tail -2 $O/sqm_a_$TAG.log; rm -rf $O/sqm_a_$TAG $O/sqm_b_$TAG;;
-    slowprof) cd /tmp; (timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/profs_$TAG -o bench -- python $R/bench.py --slow-vae --steps 1 --warmup 0 --no-cpu-baseline --no-f32-pass --no-oracle-pass --no-whole-tile-pass --no-stress-pass 2>&1 | tail -3) > $O/rocprof_slow_$TAG.log 2>&1; cd $R
+    slowprof) cd /tmp; (timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/profs_$TAG -o bench -- python $R/bench.py --slow-vae --steps 1 --warmup 0 --no-cpu-baseline --no-f32-pass --no-oracle-pass --no-whole-tile-pass --no-stress-pass --no-companions 2>&1 | tail -3) > $O/rocprof_slow_$TAG.log 2>&1; cd $R
         find $O/profs_$TAG -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_slow_$TAG.csv \; ; head -16 $O/kernel_stats_slow_$TAG.csv | cut -c1-200; rm -rf $O/profs_$TAG;;
     slow) : > $O/slow_ab_$TAG.log
         for v in 1 0 1 0; do MDTILE_SLOW_STATS=$v timeout 600 python bench.py --slow-vae --steps 2 --warmup 1 --no-oracle-pass --no-stress-pass --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys, json; d = json.loads(sys.stdin.read()); print('MDTILE_SLOW_STATS=$v  slow-mode 8K step', d['ms_per_step'], 'ms')" >> $O/slow_ab_$TAG.log 2>&1; done
