@@ -807,8 +807,15 @@ def main():
                 ref = solo(z)
             finally:
                 builtins.print = _print
-            debug_check = {"assembled_image_rel_err_vs_single_rank": float((img.float() - ref.float()).abs().max().item() / ref.float().abs().max().item()),
+            den = ref.float().abs().max().item()
+            debug_check = {"assembled_image_rel_err_vs_single_rank": float((img.float() - ref.float()).abs().max().item() / den),
                            "image_shape": list(img.shape)}
+            # per tile: which rank decoded it and how far its rectangle is from the single-rank decode (a wrong tile names its owner)
+            ins_, outs_ = hook.split_tiles(L, L)
+            owner_ = sharding.deal_tiles(ins_, world)
+            debug_check["per_tile"] = [{"tile": i, "owner": owner_[i], "in_bbox": list(ins_[i]),
+                                        "rel_err": float((img[:, :, ob[2]:ob[3], ob[0]:ob[1]].float() - ref[:, :, ob[2]:ob[3], ob[0]:ob[1]].float()).abs().max().item() / den)}
+                                       for i, ob in enumerate(outs_)]
             del ref
         del img
         sync_all()

@@ -204,17 +204,30 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // every precision mode): a lane owns two adjacent pixels of a row as packed pairs (v_pk_fma_f32), its 4 x 3 x CIN input values live in
 // registers, the weights of 128 couts sit in LDS [cout][tap][cin] and are read as wave-wide broadcasts (16 B per read, no conflicts);
 // one 8-byte store per cout and lane = 512-byte runs per wave.  Block = 4 waves = 4 rows x 128 px x 128 couts.
+//
+// Round 6: every weight sits in LDS TWICE, as the pair (w, w) the packed FMA consumes, so that no operand of the loop needs an op_sel
+// modifier.  The round-5 form kept one copy, read quads (w0 w1 w2 w3) and let hipcc broadcast each to both halves of the pair; for w1 that is
+// `v_pk_fma_f32 ... op_sel:[0,1,0]` (the LOW half of the product reads the HIGH register of the source pair).  Alone on the GPU that kernel was
+// bit-stable over every test of round 5; sharing its CU with another kernel's MFMA waves (another process on the same GPU, or another stream
+// of this one) it returned, in 43-100 % of its calls, values in which exactly that one product was missing -- low half only, lanes 48-63
+// only, a few couts per wave (probes/contention_fewcin.py, profiles/r6j: the dump of one such call is explained term by term).  The LDS
+// reads, the registers, the stores and the FMAs of every other encoding passed the same test (probes/contention_regkeep.py; forms 2-5 of the
+// investigation).  FORM 1 (PROBES twin, MDTILE_FEWCIN_FORM=1) is the round-5 kernel, kept so that the finding stays reproducible;
+// tools/asm_guard.py checks that the shipping kernel's packed FMAs carry no op_sel.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-template <int CIN>
+template <int CIN, int FORM = 0>
 __global__ __launch_bounds__(256) void k_conv3x3_fewcin(const float* __restrict__ x, const float* __restrict__ wpk, const float* __restrict__ bias,
                                                         const float* __restrict__ res, float* __restrict__ y, int Cout, int CoutP, int NCB, int H, int W) {
     constexpr int K = 9 * CIN, KP = (K + 3) & ~3;
-    __shared__ float4 wl4[128 * KP / 4];
+    constexpr int DUP = FORM == 0 ? 2 : 1;                 // copies of each weight in LDS
+    __shared__ float4 wl4[128 * KP * DUP / 4];
     float* const wl = reinterpret_cast<float*>(wl4);
     const int cb = blockIdx.z % NCB, b = blockIdx.z / NCB;
-    for (int i = threadIdx.x; i < 128 * KP; i += 256) {       // packed fp32 image [tap][cin][CoutP] -> LDS [cout][tap * CIN + cin]
+    for (int i = threadIdx.x; i < 128 * KP; i += 256) {       // packed fp32 image [tap][cin][CoutP] -> LDS [cout][tap * CIN + cin] (x DUP)
         const int co = i & 127, k = i >> 7;
-        wl[co * KP + k] = (k < K && cb * 128 + co < Cout) ? wpk[(size_t)k * CoutP + cb * 128 + co] : 0.0f;
+        const float wv = (k < K && cb * 128 + co < Cout) ? wpk[(size_t)k * CoutP + cb * 128 + co] : 0.0f;
+        if constexpr (DUP == 2) reinterpret_cast<f32x2*>(wl)[co * KP + k] = f32x2{wv, wv};
+        else wl[co * KP + k] = wv;
     }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -249,14 +262,24 @@ __global__ __launch_bounds__(256) void k_conv3x3_fewcin(const float* __restrict_
     for (int co = 0; co < nco; ++co) {      // (four couts in flight: independent FMA chains)
         const float bv = bias ? bias[cb * 128 + co] : 0.0f;
         f32x2 acc = f32x2{0.0f, 0.0f};
-        const float4* wr = wl4 + co * (KP / 4);
+        if constexpr (DUP == 2) {
+            const float4* wr = wl4 + co * (KP / 2);
 #pragma unroll
-        for (int k4 = 0; k4 < KP / 4; ++k4) {
-            const float4 w = wr[k4];
-            acc = __builtin_elementwise_fma(in[4 * k4 + 0], f32x2{w.x, w.x}, acc);
-            acc = __builtin_elementwise_fma(in[4 * k4 + 1], f32x2{w.y, w.y}, acc);
-            acc = __builtin_elementwise_fma(in[4 * k4 + 2], f32x2{w.z, w.z}, acc);
-            acc = __builtin_elementwise_fma(in[4 * k4 + 3], f32x2{w.w, w.w}, acc);
+            for (int k2 = 0; k2 < KP / 2; ++k2) {
+                const float4 w = wr[k2];      // (w[2 k2], w[2 k2], w[2 k2 + 1], w[2 k2 + 1]): two ready-made pairs
+                acc = __builtin_elementwise_fma(in[2 * k2 + 0], f32x2{w.x, w.y}, acc);
+                acc = __builtin_elementwise_fma(in[2 * k2 + 1], f32x2{w.z, w.w}, acc);
+            }
+        } else {
+            const float4* wr = wl4 + co * (KP / 4);
+#pragma unroll
+            for (int k4 = 0; k4 < KP / 4; ++k4) {
+                const float4 w = wr[k4];
+                acc = __builtin_elementwise_fma(in[4 * k4 + 0], f32x2{w.x, w.x}, acc);
+                acc = __builtin_elementwise_fma(in[4 * k4 + 1], f32x2{w.y, w.y}, acc);
+                acc = __builtin_elementwise_fma(in[4 * k4 + 2], f32x2{w.z, w.z}, acc);
+                acc = __builtin_elementwise_fma(in[4 * k4 + 3], f32x2{w.w, w.w}, acc);
+            }
         }
         acc += f32x2{bv, bv};
         float* yp = yb + (size_t)co * HW;
@@ -390,8 +413,16 @@ extern "C" int mdtile_conv2d(const float* d_x, const float* d_w_packed, const fl
         const int ncb = (cout + 127) / 128;
         MDT_CHECK_ARG((size_t)B * ncb <= 65535 && (H + 3) / 4 <= 65535, "mdtile_conv2d: conv_in grid too large (B=%d cout=%d H=%d)", B, cout, H);
         dim3 grid((W + 127) / 128, (H + 3) / 4, B * ncb), block(256);
-        if (cin == 3) hipLaunchKernelGGL(k_conv3x3_fewcin<3>, grid, block, 0, s, d_x, d_w_packed, d_bias, d_residual, d_y, cout, P.CoutP, ncb, H, W);
-        else hipLaunchKernelGGL(k_conv3x3_fewcin<4>, grid, block, 0, s, d_x, d_w_packed, d_bias, d_residual, d_y, cout, P.CoutP, ncb, H, W);
+        if constexpr (kProbes) {      // PROBES twin, MDTILE_FEWCIN_FORM=1: the round-5 kernel (one copy of the weights, op_sel broadcasts; see above)
+            if (const char* e = probe_env("MDTILE_FEWCIN_FORM"); e && atoi(e) == 1) {
+                if (cin == 3) hipLaunchKernelGGL((k_conv3x3_fewcin<3, 1>), grid, block, 0, s, d_x, d_w_packed, d_bias, d_residual, d_y, cout, P.CoutP, ncb, H, W);
+                else hipLaunchKernelGGL((k_conv3x3_fewcin<4, 1>), grid, block, 0, s, d_x, d_w_packed, d_bias, d_residual, d_y, cout, P.CoutP, ncb, H, W);
+                MDT_LAUNCH_CHECK();
+                return MDTILE_OK;
+            }
+        }
+        if (cin == 3) hipLaunchKernelGGL((k_conv3x3_fewcin<3>), grid, block, 0, s, d_x, d_w_packed, d_bias, d_residual, d_y, cout, P.CoutP, ncb, H, W);
+        else hipLaunchKernelGGL((k_conv3x3_fewcin<4>), grid, block, 0, s, d_x, d_w_packed, d_bias, d_residual, d_y, cout, P.CoutP, ncb, H, W);
         MDT_LAUNCH_CHECK();
         return MDTILE_OK;
     }

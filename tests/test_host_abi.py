@@ -91,7 +91,7 @@ def test_dma_protocol_in_the_device_assembly():
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asm_guard.py")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout
-    assert r.stdout.count(" ok") == 12, r.stdout      # 2 streaming 1x1 + 3 record (one block per CU) + 2 of them with statistics + 2 record (two blocks per CU) + 3 attention
+    assert r.stdout.count(" ok") == 14, r.stdout      # 2 conv_in (no op_sel on packed fp32) + 2 streaming 1x1 + 3 record (one block per CU) + 2 of them with statistics + 2 record (two blocks per CU) + 3 attention
     # (the dripped-epilogue kernel left the shipping library in round 6: probes/csrc/, checked by `tools/asm_guard.py --probes`)
 
 

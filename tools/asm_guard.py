@@ -148,6 +148,21 @@ def main() -> int:
             errs.append(f"kernel {sub} not found in the device assembly")
             continue
         errs += check_kernel(hit[0], table[hit[0]], expect)
+    # conv_in (csrc/vae_conv.hip: k_conv3x3_fewcin): no packed-fp32 instruction of the shipping form may read the HIGH register of a pair for
+    # the LOW half of its result (`op_sel:[..1..]`) -- the encoding that dropped single products when the kernel shared a CU with another
+    # kernel's MFMA waves (round 6, profiles/r6j).  The shipping form keeps every weight in LDS as a ready-made pair and needs none.
+    cin = kernels(device_asm(os.path.join(CSRC, "vae_conv.hip")))
+    for cinv in (3, 4):
+        hit = [n for n in cin if f"k_conv3x3_fewcinILi{cinv}ELi0E" in n]
+        if not hit:
+            errs.append(f"kernel k_conv3x3_fewcin<{cinv}, 0> not found in the device assembly")
+            continue
+        ins = cin[hit[0]]
+        pk = [l for l in ins if l.startswith("v_pk_")]
+        bad = [l for l in pk if re.search(r"op_sel:\[", l)]
+        print(f"{hit[0][:70]:70s} {len(ins):6d} instr  {len(pk):3d} packed-fp32 instructions, {len(bad)} with op_sel  {'ok' if pk and not bad else 'FAIL'}")
+        if not pk or bad:
+            errs.append(f"{hit[0]}: {len(bad)} packed instructions carry op_sel (first: {bad[:1]})")
     for e in errs:
         print("ASM GUARD:", e)
     return 1 if errs else 0
