@@ -36,8 +36,8 @@ struct ConvParams {
 
 // S = 2: ldm's Downsample (F.pad(x, (0,1,0,1)) then a stride-2 3x3 conv without padding; the encoder's 'downsample' task,
 // scripts/tilevae.py:155-171): out[y][x] = sum w[dy][dx] in[2y+dy][2x+dx], zero beyond the last input row / column.
-template <int KS, int KC, int WP, int WC, int RP, int RC, bool TOKMAJ, int S = 1>
-__global__ __launch_bounds__(256) void k_conv(const ConvParams P) {
+template <int KS, int KC, int WP, int WC, int RP, int RC, bool TOKMAJ, int S = 1, int MINB = 1>
+__global__ __launch_bounds__(256, MINB) void k_conv(const ConvParams P) {
     static_assert(WP * WC == 4 && WP * RP == 8, "4 waves cover 8 rows");
     constexpr int PAD = S == 1 ? KS / 2 : 0, ROWS = 7 * S + KS, TWP = 31 * S + KS, TAPS = KS * KS, BN = WC * RC * 32;
     constexpr int E_IN = KC * ROWS * TWP, E_IN_P = (E_IN + 3) & ~3, E_WT = TAPS * KC * BN;
@@ -298,15 +298,15 @@ __global__ __launch_bounds__(256) void k_conv3x3_fewcin(const float* __restrict_
 
 static bool conv_fewcin_eligible(int cin, int ksize, int up, int out_layout) { return ksize == 3 && (cin == 3 || cin == 4) && !up && out_layout == 0; }
 
-template <int KS, int KC, int WP, int WC, int RP, int RC>
+template <int KS, int KC, int WP, int WC, int RP, int RC, int MINB = 1>
 int launch_conv(ConvParams& P, int out_layout, hipStream_t s) {
     constexpr int BN = WC * RC * 32;
     P.PX = (P.W + 31) / 32;
     P.ptiles = P.PX * ((P.H + 7) / 8);
     P.NCB = (P.CoutP + BN - 1) / BN;
     dim3 grid(((P.ptiles + 7) / 8) * 8 * P.NCB, P.B), block(256);
-    if (out_layout == 1) hipLaunchKernelGGL((k_conv<KS, KC, WP, WC, RP, RC, true>), grid, block, 0, s, P);
-    else hipLaunchKernelGGL((k_conv<KS, KC, WP, WC, RP, RC, false>), grid, block, 0, s, P);
+    if (out_layout == 1) hipLaunchKernelGGL((k_conv<KS, KC, WP, WC, RP, RC, true, 1, MINB>), grid, block, 0, s, P);
+    else hipLaunchKernelGGL((k_conv<KS, KC, WP, WC, RP, RC, false, 1, MINB>), grid, block, 0, s, P);
     MDT_LAUNCH_CHECK();
     return MDTILE_OK;
 }
@@ -428,6 +428,13 @@ extern "C" int mdtile_conv2d(const float* d_x, const float* d_w_packed, const fl
     }
     const bool wide = P.CoutP > 64;
     if (ksize == 3) {
+        if constexpr (kProbes) {
+            if (const char* e = probe_env("MDTILE_CONVF32_FORM")) {
+                if (wide && atoi(e) == 1) return launch_conv<3, 4, 2, 2, 4, 2, 2>(P, out_layout, s);      // 4-channel slabs, two blocks per CU
+                if (wide && atoi(e) == 2) return launch_conv<3, 4, 2, 2, 4, 2, 1>(P, out_layout, s);
+                if (wide && atoi(e) == 3) return launch_conv<3, 2, 2, 2, 4, 2, 2>(P, out_layout, s);
+            }
+        }
         if (wide) return launch_conv<3, 8, 2, 2, 4, 2>(P, out_layout, s);
         return launch_conv<3, 8, 4, 1, 2, 1>(P, out_layout, s);
     }

@@ -5,6 +5,7 @@
 #   sp8      `python bench.py --gpus 8 --single-process --steps 1 --warmup 1` (cuda:0 listed eight times)
 #   blendab  probes/blend_r6_ab.py: the shipping blend kernel, the LDS-staged form and the stream-copy floor, cold and warm, same process
 #   attnab   probes/attn_ab.py <other .so>: two builds of the attention kernel alternated in one process
+#   contend  the co-residency probes (probes/contention_*.py);   convf32  probes/convf32_probe.py over the block shapes under test
 #   chk:<pytest args with + for spaces>   an ad-hoc pytest selection
 TAG=${1:-r6}; shift
 WHAT=${*:-"tests smoke bench"}
@@ -42,6 +43,13 @@ for w in $WHAT; do
           if [ $lib = base ]; then export MDTILE_AB_LIB=$R/probes/_ab/libmdtile_c1x1_base.so; else unset MDTILE_AB_LIB; fi
           (PROBE_B=$b timeout 300 python probes/conv1x1_probe.py 2>&1 | grep "^1x1") >> $O/conv1x1_ab_$TAG.log 2>&1; done; done; done; unset MDTILE_AB_LIB
         cat $O/conv1x1_ab_$TAG.log;;
+    contend) # conv_in / the blend / the whole decode sharing the GPU with other processes' and streams' kernels (profiles/r6j)
+        { for form in "" 1; do for mode in "mix:handover" "mix" "same:handover"; do echo "=== MDTILE_FEWCIN_FORM=$form, $mode"
+            MDTILE_FEWCIN_FORM=$form timeout 300 python probes/contention_fewcin.py 4 100 "$mode" 2>&1 | grep -v "amdgpu\|failure\|wrong value\|^\[probes\]" | tail -1; done; done
+          timeout 300 python probes/contention_regkeep.py 4 100 mix:handover 2>&1 | grep -v "amdgpu\|^\[probes\]"
+          timeout 600 python probes/contention_blend.py 4 200 mix:handover 2>&1 | grep -v "amdgpu\|^\[probes\]"
+          timeout 900 python probes/contention_determinism.py 4 3 512 256 2>&1 | grep -v amdgpu | tail -3; } > $O/contention_$TAG.log 2>&1; cat $O/contention_$TAG.log | cut -c1-300;;
+    convf32) for f in "" 1 2 3; do MDTILE_CONVF32_FORM=$f timeout 600 python probes/convf32_probe.py 2>&1 | grep "^form"; done | tee $O/convf32_probe_$TAG.log;;
     chk:*) sel=${w#chk:}; (timeout 1800 python -m pytest ${sel//+/ } -m gpu -q --tb=short -p no:cacheprovider -s 2>&1 | grep -v "Tiled VAE\|amdgpu.ids\|Sampling" | tail -50) > $O/pytest_chk_$TAG.log 2>&1; tail -40 $O/pytest_chk_$TAG.log;;
     *) bash $R/tools/gpu_r5.sh $TAG $w;;
   esac
