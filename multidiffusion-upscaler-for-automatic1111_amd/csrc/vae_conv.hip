@@ -428,13 +428,18 @@ extern "C" int mdtile_conv2d(const float* d_x, const float* d_w_packed, const fl
     }
     const bool wide = P.CoutP > 64;
     if (ksize == 3) {
+        // Block shape of the wide exact-fp32 conv (round 6, probes/convf32_probe.py, profiles/r6l): 8-channel slabs cost 95 KB of LDS and 288
+        // registers = ONE 4-wave block per CU; 2-channel slabs (24 KB, 188 registers under __launch_bounds__(256, 2)) run two blocks per
+        // CU and hide each other's barriers: 116 -> 126 TF at 256 channels / 556^2, 108 -> 123 TF at 128 / 1112^2, 120 -> 129 TF at
+        // 512 -> 256 and at four stacked 512 -> 512 tiles of 278^2 (the decode's stacking depth).  ONE such tile alone loses (118 -> 105 TF:
+        // its 1260 blocks fill 512 slots 2.46 times); the rule does not look at the batch, so a tile decoded in a stack and alone takes
+        // the same kernel and the same summation order.
+        int form = 3;
         if constexpr (kProbes) {
-            if (const char* e = probe_env("MDTILE_CONVF32_FORM")) {
-                if (wide && atoi(e) == 1) return launch_conv<3, 4, 2, 2, 4, 2, 2>(P, out_layout, s);      // 4-channel slabs, two blocks per CU
-                if (wide && atoi(e) == 2) return launch_conv<3, 4, 2, 2, 4, 2, 1>(P, out_layout, s);
-                if (wide && atoi(e) == 3) return launch_conv<3, 2, 2, 2, 4, 2, 2>(P, out_layout, s);
-            }
+            if (const char* e = probe_env("MDTILE_CONVF32_FORM")) form = atoi(e);
         }
+        if (wide && form == 1) return launch_conv<3, 4, 2, 2, 4, 2, 2>(P, out_layout, s);
+        if (wide && form == 3) return launch_conv<3, 2, 2, 2, 4, 2, 2>(P, out_layout, s);
         if (wide) return launch_conv<3, 8, 2, 2, 4, 2>(P, out_layout, s);
         return launch_conv<3, 8, 4, 1, 2, 1>(P, out_layout, s);
     }

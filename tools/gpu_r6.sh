@@ -49,7 +49,7 @@ for w in $WHAT; do
           timeout 300 python probes/contention_regkeep.py 4 100 mix:handover 2>&1 | grep -v "amdgpu\|^\[probes\]"
           timeout 600 python probes/contention_blend.py 4 200 mix:handover 2>&1 | grep -v "amdgpu\|^\[probes\]"
           timeout 900 python probes/contention_determinism.py 4 3 512 256 2>&1 | grep -v amdgpu | tail -3; } > $O/contention_$TAG.log 2>&1; cat $O/contention_$TAG.log | cut -c1-300;;
-    convf32) for f in "" 1 2 3; do MDTILE_CONVF32_FORM=$f timeout 600 python probes/convf32_probe.py 2>&1 | grep "^form"; done | tee $O/convf32_probe_$TAG.log;;
+    convf32) for f in "" 0 1 3; do MDTILE_CONVF32_FORM=$f timeout 600 python probes/convf32_probe.py 2>&1 | grep "^form"; done | tee $O/convf32_probe_$TAG.log;;
     chk:*) sel=${w#chk:}; (timeout 1800 python -m pytest ${sel//+/ } -m gpu -q --tb=short -p no:cacheprovider -s 2>&1 | grep -v "Tiled VAE\|amdgpu.ids\|Sampling" | tail -50) > $O/pytest_chk_$TAG.log 2>&1; tail -40 $O/pytest_chk_$TAG.log;;
     *) bash $R/tools/gpu_r5.sh $TAG $w;;
   esac
