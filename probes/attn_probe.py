@@ -10,6 +10,7 @@ if os.environ.get("MDTILE_AB_LIB"):      # another build of the library (counter
 dev = torch.device("cuda:0")
 ZEROS = "--zeros" in sys.argv     # all-zero q / k / v: same instruction stream, no operand toggling (DVFS / power check)
 QUICK = "--quick" in sys.argv     # one mid-size problem, split-bf16 kernel only (counter passes)
+EXACT_ONLY = "--exact-only" in sys.argv     # the exact-fp32 kernel only (counter passes of k_attn)
 Ts = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or ([30000] if QUICK else [7396, 30000, 71168, 77284])
 C = 512
 for T in Ts:
@@ -23,7 +24,7 @@ for T in Ts:
     line = f"T={T:6d} C={C}: "
     outs = {}
     for exact in (False, True):
-        if exact and (T > 40000 or QUICK):
+        if (exact and (T > 40000 or QUICK)) or (EXACT_ONLY and not exact):
             continue
         o = E.vae_attn(q, k, v, scale, exact=exact)
         torch.cuda.synchronize()

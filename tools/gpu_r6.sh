@@ -49,6 +49,10 @@ for w in $WHAT; do
           timeout 300 python probes/contention_regkeep.py 4 100 mix:handover 2>&1 | grep -v "amdgpu\|^\[probes\]"
           timeout 600 python probes/contention_blend.py 4 200 mix:handover 2>&1 | grep -v "amdgpu\|^\[probes\]"
           timeout 900 python probes/contention_determinism.py 4 3 512 256 2>&1 | grep -v amdgpu | tail -3; } > $O/contention_$TAG.log 2>&1; cat $O/contention_$TAG.log | cut -c1-300;;
+    sqattnf32) cd /tmp      # SQ / GRBM counters of the exact-fp32 attention kernel (k_attn<4>, csrc/vae_attn.hip) at T = 30 000
+        (timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $O/sqa_$TAG -o p -- python $R/probes/attn_probe.py 30000 --exact-only 2>&1 | grep "^T=") > $O/sq_attnf32_$TAG.log 2>&1
+        (timeout 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/sqb_$TAG -o p -- python $R/probes/attn_probe.py 30000 --exact-only 2>&1 | grep "^T=") >> $O/sq_attnf32_$TAG.log 2>&1
+        cd $R; python tools/pmc_sq.py $O/pmc_sq_attnf32_$TAG.json $O/sqa_$TAG $O/sqb_$TAG 2>&1 | grep "k_attn\|kernel" | head -6 | tee -a $O/sq_attnf32_$TAG.log; rm -rf $O/sqa_$TAG $O/sqb_$TAG;;
     convf32) for f in "" 0 1 3; do MDTILE_CONVF32_FORM=$f timeout 600 python probes/convf32_probe.py 2>&1 | grep "^form"; done | tee $O/convf32_probe_$TAG.log;;
     chk:*) sel=${w#chk:}; (timeout 1800 python -m pytest ${sel//+/ } -m gpu -q --tb=short -p no:cacheprovider -s 2>&1 | grep -v "Tiled VAE\|amdgpu.ids\|Sampling" | tail -50) > $O/pytest_chk_$TAG.log 2>&1; tail -40 $O/pytest_chk_$TAG.log;;
     *) bash $R/tools/gpu_r5.sh $TAG $w;;
