@@ -3,9 +3,14 @@
 form whenever its waves shared a CU with another kernel's MFMA waves -- another stream of the same process is enough (DESIGN.md 3.5,
 profiles/r6j).  Every other GPU test runs its kernels alone on the chip, so this one overlaps conv_in with hand-over 3x3 convs on a side
 stream (the neighbour that produced wrong values in 100 of 100 launches) and asks for the bit pattern of the launch that ran alone.
-The blend (bit-exact by contract, packed-fp32 `op_sel` encodings in its MoD path) gets the same treatment."""
+The blend (bit-exact by contract, packed-fp32 `op_sel` encodings in its MoD path) and a whole tiled decode (every kernel of the VAE path,
+fast and slow mode, decoder and encoder) get the same treatment."""
+import threading
+
 import pytest
 import torch
+
+from hostsim import ldm_decoder as ld
 
 pytestmark = pytest.mark.gpu
 
@@ -72,4 +77,45 @@ def test_blend_is_bit_stable_next_to_mfma_kernels(plugin, cuda, method):
         bad += int(not torch.equal(blend.out, alone))
     side.synchronize()
     print(f"blend ({method}, 96 / 48 grid) overlapped with hand-over convs: {bad} of 200 launches differ")
+    assert bad == 0
+
+
+@pytest.mark.parametrize("what", ["decode-fast", "decode-slow", "encode-fast"])
+def test_tiled_vae_is_bit_stable_next_to_mfma_kernels(plugin, cuda, what):
+    """vae_tile_forward (scripts/tilevae.py:577-737 upstream) of a 160x160 latent at decoder tile 64 (9 tiles, T = 7 396) / a 1280^2 image
+    at encoder tile 512, alone and with another THREAD of the process launching hand-over convs on its own stream the whole time: the
+    two results must be the same bits (the decode is deterministic: same tiles, same stacking, same kernels)."""
+    E, dev = plugin.engine, cuda
+    dec = what.startswith("decode")
+    fast = what.endswith("fast")
+    net = (ld.make_decoder(5) if dec else ld.make_encoder(5)).to(dev)
+    net.original_forward = net.forward
+    hook = plugin.tilevae.VAEHook(net, 64 if dec else 512, is_decoder=dec, fast_decoder=fast, fast_encoder=fast, color_fix=False)
+    torch.manual_seed(17)
+    x = (torch.randn(1, 4, 160, 160) if dec else torch.randn(1, 3, 1280, 1280)).to(dev)
+    alone = hook(x).clone()
+    torch.cuda.synchronize()
+    busy = _neighbours(E, dev)
+    stop = threading.Event()
+
+    def load():
+        torch.cuda.set_device(dev)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            while not stop.is_set():
+                busy()
+                side.synchronize()
+
+    th = threading.Thread(target=load)
+    th.start()
+    try:
+        bad = 0
+        for _ in range(3):
+            y = hook(x)
+            torch.cuda.synchronize()
+            bad += int(not torch.equal(y, alone))
+    finally:
+        stop.set()
+        th.join()
+    print(f"{what}: {bad} of 3 runs next to hand-over convs on another stream differ from the run that had the chip alone")
     assert bad == 0
