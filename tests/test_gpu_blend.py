@@ -137,6 +137,39 @@ def test_blend_full_size_vs_oracle(plugin, cuda, name, method, W, H, tw, th, ov,
     assert (ident - x).abs().max().item() < 2e-6
 
 
+def _random_geometry(seed):
+    """Canvas, tile, overlap, tile batch, method and image batch drawn from what the delegates accept (upstream's sliders: tile 16..256 in
+    steps of 16 by the UI, any integer through the API; overlap 0..tile - 4): odd canvases, tiles larger than the canvas (clamped like
+    upstream's split_bboxes), ragged last rows / columns, origins of every alignment."""
+    import random
+    r = random.Random(seed)
+    W, H = r.randint(24, 520), r.randint(24, 520)
+    tw, th = r.choice([16, 24, 40, 64, 72, 96, 100, 128, 160]), r.choice([16, 24, 40, 64, 72, 96, 100, 128, 160])
+    ov = r.randint(0, max(0, min(tw, th, W, H) - 4))
+    return ("md", "mod")[seed % 2], W, H, tw, th, ov, r.randint(1, 8), r.randint(1, 3)
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_blend_random_geometries_vs_oracle(plugin, cuda, seed):
+    """Bit-exact against the oracle on 32 seeded random geometries: which of the blend kernels runs (k_blend's vector / element path,
+    k_blend_lds on grids with odd origins, the packed-pointer form) follows from the geometry, the sum must not."""
+    method, W, H, tw, th, ov, bs, N = _random_geometry(seed)
+    d = _delegate(plugin, method, W, H, tw, th, ov, bs)
+    o = bo.BlendOracle(method, W, H, tw, th, ov, bs)
+    torch.manual_seed(seed)
+    x = torch.randn(N, 4, H, W)
+    out = _evaluate(plugin, d, method, x.to(cuda)).cpu()
+    ref = o.evaluate(x, bo.synthetic_denoiser)
+    assert torch.equal(d.weights.cpu(), o.weights), (method, W, H, tw, th, ov, bs, N)
+    # (Mixture of Diffusers with small tiles: upstream's Gaussian underflows to 0 on the outermost rows, its 1 / weights is inf there and
+    # the blended pixel NaN -- upstream behaviour, reproduced: NaNs must sit at the same pixels, everything else must be the same bits)
+    nan = torch.isnan(ref)
+    assert torch.equal(torch.isnan(out), nan), f"{(method, W, H, tw, th, ov, bs, N)}: NaN pattern differs"
+    z = torch.zeros(())
+    assert torch.equal(torch.where(nan, z, out), torch.where(nan, z, ref)), \
+        f"{(method, W, H, tw, th, ov, bs, N)}: max abs diff {(torch.where(nan, z, out) - torch.where(nan, z, ref)).abs().max().item()}"
+
+
 def test_blend_cfg5_regions_vs_oracle(plugin, cuda):
     regs = [(0.0, 0.0, 0.4, 1.0, "Background", 0.2), (0.3, 0.0, 0.4, 1.0, "Background", 0.2), (0.6, 0.1, 0.4, 0.8, "Foreground", 0.2)]
     W, H = 512, 128
