@@ -285,6 +285,37 @@ def test_tiled_decode_full_width_decoder(plugin, cuda, fast):
     assert err < 2e-4, f"full-width tiled decode (fast={fast}): rel err {err}"
 
 
+def _random_vae_case(seed):
+    import random
+    r = random.Random(1000 + seed)
+    dec = seed % 3 != 2                       # two decodes for one encode
+    if dec:
+        H, W, ts = r.randint(30, 120), r.randint(30, 120), r.choice([8, 12, 16, 24, 32, 48])
+    else:
+        H, W, ts = r.randint(200, 700), r.randint(200, 700), r.choice([64, 96, 128, 200, 256])
+    return dec, H, W, ts, bool(r.getrandbits(1)), r.randint(1, 2), (not dec) and bool(r.getrandbits(1))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 4, 5, 6, 7, 8, 9, 11, 12, 13, 14, 15, 16, 17])      # (0, 3, 10: the CPU oracle needs 7-30 s each)
+def test_tiled_vae_random_geometries_vs_cpu_oracle(plugin, cuda, seed):
+    """15 seeded random (size, tile, mode, batch) cases on the reduced-width networks against the CPU oracle (upstream's split_tiles,
+    estimator, task queue, crop: scripts/tilevae.py:375-388, 464-505, 577-737): odd sizes, one-tile-wide grids, tiles larger than one
+    axis, ragged last tiles, stacked and single tiles, live windows on every geometry."""
+    dec, H, W, ts, fast, N, color_fix = _random_vae_case(seed)
+    net_cpu = ld.make_decoder(seed, small=True) if dec else ld.make_encoder(seed, small=True)
+    torch.manual_seed(seed)
+    x = torch.randn(N, 4 if dec else 3, H, W)
+    ref = vo.tiled_forward(net_cpu, x, ts, fast, is_decoder=dec, color_fix=color_fix)
+    net = (ld.make_decoder(seed, small=True) if dec else ld.make_encoder(seed, small=True)).to(cuda)
+    net.original_forward = net.forward
+    hook = plugin.tilevae.VAEHook(net, ts, is_decoder=dec, fast_decoder=fast, fast_encoder=fast, color_fix=color_fix)
+    out = hook(x.to(cuda)).cpu()
+    assert out.shape == ref.shape
+    err = _rel(out, ref)
+    print(f"{'decode' if dec else 'encode'} {N} x {H}x{W} tile {ts} fast={fast} color_fix={color_fix}: rel err {err:.2e}")
+    assert err < 2e-4, f"{(dec, H, W, ts, fast, N, color_fix)}: rel err {err}"
+
+
 def test_untiled_small_input_takes_original_forward(plugin, cuda):
     dec = ld.make_decoder(0, small=True).to(cuda)
     dec.original_forward = dec.forward
